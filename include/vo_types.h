@@ -1,0 +1,67 @@
+/* vo_types.h — plain-C data carriers that cross the drop-in boundary.
+ *
+ * Layouts mirror the OpenCV 3.4 types the reference's interfaces move around
+ * (reference: src/features/feature_detector.h:17-25, src/matcher/matcher.h:11,
+ * src/visual_odometry/vo_frame.h:14-45), so a cv-typed adapter can memcpy them.
+ */
+#ifndef VO_TYPES_H
+#define VO_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint: {Point2f pt; float size, angle, response; int octave, class_id;} — 28 bytes. */
+typedef struct vo_keypoint {
+    float x, y;
+    float size;
+    float angle;     /* degrees in [0,360), -1 when not computed */
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} vo_keypoint;
+
+/* cv::DMatch: {int queryIdx, trainIdx, imgIdx; float distance;} — 16 bytes. */
+typedef struct vo_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} vo_dmatch;
+
+/* cv::ORB::create(...) arguments, in cv order. The reference fixes nfeatures only
+ * (src/features/feature_detector.cpp:5 -> 5000; src/features/cuda/feature_detector.cpp:7 -> 2000);
+ * every other field keeps the cv default (vo_orb_params_default). */
+typedef struct vo_orb_params {
+    int32_t nfeatures;
+    float scale_factor;    /* 1.2f */
+    int32_t nlevels;       /* 8 */
+    int32_t edge_threshold;/* 31 */
+    int32_t first_level;   /* 0 (only 0 supported) */
+    int32_t wta_k;         /* 2 (only 2 supported) */
+    int32_t score_type;    /* 0 = HARRIS_SCORE (only 0 supported) */
+    int32_t patch_size;    /* 31 (only 31 supported) */
+    int32_t fast_threshold;/* 20 */
+} vo_orb_params;
+
+/* cv method enum values used by findEssentialMat (reference: src/matcher/matcher.cpp:42 RANSAC,
+ * src/visual_odometry/vo_pose.h:14 LMEDS). */
+#define VO_LMEDS 4
+#define VO_RANSAC 8
+
+/* status codes */
+#define VO_OK 0
+#define VO_ERR_INVALID 1    /* bad argument (null pointer, size out of range, unsupported param) */
+#define VO_ERR_CAPACITY 2   /* an output or the context workspace is too small */
+#define VO_ERR_DEVICE 3     /* HIP runtime error */
+#define VO_ERR_FAILED 4     /* the estimator found no model (cv returns an empty Mat) */
+
+#define VO_ORB_MAX_LEVELS 16
+#define VO_DESC_BYTES 32
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_TYPES_H */
