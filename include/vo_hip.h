@@ -1,0 +1,163 @@
+/* vo_hip.h — C ABI of libvo_hip.so, the MI355X (gfx950) implementation of the reference's
+ * per-frame-pair hot path.
+ *
+ * The reference (maym86/visual_odometry) has no FFI: its seam is a compile-time source-variant
+ * switch between src/features/ and src/features/cuda/ with identical C++ signatures
+ * (reference: CMakeLists.txt:33-37, src/visual_odometry/visual_odometry.h:8-14).  A third
+ * variant forwards those same methods to the entry points below (INTEGRATION.md shows the
+ * adapter); each entry point cites the reference call it replaces.
+ *
+ * Conventions: plain pointers and sizes, caller-allocated outputs with capacity + count-out,
+ * int status (VO_OK == 0), vo_last_error(ctx) for the message.  Unless the name ends in _dev,
+ * pointers are HOST pointers and the call is synchronous (upload, kernels, download).  One
+ * vo_ctx = one HIP stream + workspace; a ctx must not be used from two threads at once.
+ * The library never falls back to the CPU: without a usable HIP device vo_ctx_create fails.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include "vo_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+typedef struct vo_limits {
+    int32_t max_width;    /* largest image width  (default 1241) */
+    int32_t max_height;   /* largest image height (default 376)  */
+    int32_t max_features; /* largest ORB nfeatures / descriptor count per set (default 8192) */
+    int32_t max_points;   /* largest point count for E estimation / recoverPose (default 8192) */
+    int32_t max_batch;    /* frames per vo_pairs_run_dev call (default 64) */
+} vo_limits;
+
+void vo_limits_default(vo_limits* l);
+
+/* No reference counterpart (the reference keeps cv::Ptr detectors as members:
+ * src/features/feature_detector.cpp:3-10). limits may be NULL. */
+int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+int vo_ctx_synchronize(vo_ctx* ctx);
+
+void vo_orb_params_default(vo_orb_params* p, int nfeatures);
+
+/* ---- features: replaces FeatureDetector (src/features/feature_detector.cpp) ------------- */
+
+/* detector_->detect(image, keypoints) with FastFeatureDetector::create(thr, nms, TYPE_9_16)
+ * reference: src/features/feature_detector.cpp:4,15,24 (cuda variant :6,17,26).
+ * Keypoints come back in cv's order (rows ascending, x ascending). *n is the true count;
+ * VO_ERR_CAPACITY if it exceeds cap (the first cap are written). */
+int vo_fast_detect(vo_ctx* ctx, const uint8_t* gray, int w, int h, int stride, int threshold,
+                   int nms, vo_keypoint* out, int cap, int* n);
+
+/* descriptor_->detectAndCompute(image, noArray(), keypoints, descriptors)
+ * reference: src/features/feature_detector.cpp:5,27-29 (cuda variant :7,31-35).
+ * desc is cap x 32 bytes. Up to nfeatures plus response ties are returned (cv semantics). */
+int vo_orb_detect_compute(vo_ctx* ctx, const uint8_t* gray, int w, int h, int stride,
+                          const vo_orb_params* p, vo_keypoint* kp, uint8_t* desc, int cap, int* n);
+
+/* descriptor_->compute(image, keypoints, descriptors) on caller keypoints
+ * reference: src/features/feature_detector.cpp:32-42. Keypoints closer than edge_threshold to
+ * the border are dropped (list compacted in place, *n updated), angle/octave are used as given. */
+int vo_orb_compute(vo_ctx* ctx, const uint8_t* gray, int w, int h, int stride,
+                   const vo_orb_params* p, vo_keypoint* kp_inout, int* n_inout, uint8_t* desc);
+
+/* ---- matcher: replaces the body of matcher() (src/matcher/matcher.cpp) ------------------- */
+
+/* matcher->knnMatch(desc_q, desc_t, matches, 2) with "BruteForce-Hamming"
+ * reference: src/matcher/matcher.cpp:10,17. out is nq x 2 (row-major), n_valid[i] = min(2, nt)
+ * (n_valid may be NULL). desc_bytes <= 64. Ties keep the lower train index first. */
+int vo_knn2_hamming(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes,
+                    vo_dmatch* out, int* n_valid);
+
+/* ratio test d0 < ratio*d1 and ||p0-p1|| < max_disp, order preserving
+ * reference: src/matcher/matcher.cpp:23-38 (kMatchRatio :6, 200 px :30). Rows with fewer than
+ * two neighbours are skipped (undefined behaviour in the reference). */
+int vo_match_filter(vo_ctx* ctx, const vo_dmatch* knn, const int* n_valid, int nq,
+                    const vo_keypoint* kq, const vo_keypoint* kt, float ratio, float max_disp,
+                    vo_dmatch* good, int* n_good);
+
+/* ---- sfm: replaces the cv calls in updatePose() and matcher() ---------------------------- */
+
+/* cv::findEssentialMat(p0, p1, K, method, prob, threshold, mask)
+ * reference: src/matcher/matcher.cpp:42 (VO_RANSAC, 0.999, 1.0),
+ *            src/visual_odometry/vo_pose.h:14 (VO_LMEDS, 0.999, 1.0).
+ * p0/p1: n x 2 float pixels; K: 3x3 row-major; seed: cv::RNG seed (cv uses (uint64)-1);
+ * max_iters: 1000 in cv 3.4.2. E: 3x3 row-major, unit Frobenius norm; mask: n bytes of 0/1.
+ * Returns VO_ERR_FAILED (E zeroed, mask zeroed) where cv returns an empty matrix. */
+int vo_find_essential(vo_ctx* ctx, const float* p0, const float* p1, int n, const double* K,
+                      int method, double prob, double threshold, uint64_t seed, int max_iters,
+                      double* E, uint8_t* mask);
+
+/* cv::recoverPose(E, p0, p1, K, R, t, distanceThresh, mask, triangulatedPoints)
+ * reference: src/visual_odometry/vo_pose.h:19. mask_inout (n bytes) may be NULL; pts4d (4 x n
+ * row-major, un-normalised homogeneous points of the winning candidate) may be NULL. */
+int vo_recover_pose(vo_ctx* ctx, const double* E, const float* p0, const float* p1, int n,
+                    const double* K, double dist_thresh, uint8_t* mask_inout, double* R, double* t,
+                    double* pts4d, int* n_good);
+
+/* triangulate(points0, points1, P0, P1): cv::triangulatePoints + points4DToVec
+ * reference: src/sfm/triangulation.cpp:46-66,13-22. pts3d: n x 3. */
+int vo_triangulate(vo_ctx* ctx, const float* p0, const float* p1, int n, const double* P0,
+                   const double* P1, double* pts3d);
+
+/* getProjectionMatrix(K, pose): K [R^T | -R^T t]; reference: src/sfm/triangulation.cpp:34-44.
+ * Twelve flops: computed on the host. */
+void vo_projection_matrix(const double* K, const double* pose, double* P);
+
+/* ---- device-resident batched frame-pair path --------------------------------------------
+ * One call runs, for n_frames consecutive frames already resident in HBM, ORB detectAndCompute
+ * on every frame and, for each consecutive pair (i, i+1): knnMatch(k=2) + ratio/displacement
+ * filter + findEssentialMat(RANSAC) (the body of matcher(), src/matcher/matcher.cpp:13-50)
+ * followed by recoverPose on the filtered matches (src/visual_odometry/vo_pose.h:19).
+ * d_frames: DEVICE pointer, n_frames images of h rows with `stride` bytes per row, frame i at
+ * d_frames + i*frame_stride. results: HOST array of n_frames-1 entries. */
+typedef struct vo_pair_params {
+    vo_orb_params orb;
+    float ratio;         /* 0.7f */
+    float max_disp;      /* 200 */
+    double prob;         /* 0.999 */
+    double threshold;    /* 1.0 */
+    double dist_thresh;  /* 200 */
+    uint64_t seed;       /* (uint64)-1 */
+    int32_t max_iters;   /* 1000 */
+    int32_t reserved;
+} vo_pair_params;
+
+typedef struct vo_pair_result {
+    int32_t n_kp0, n_kp1;     /* ORB keypoints in frame i, i+1 */
+    int32_t n_good;           /* matches after ratio + displacement filter */
+    int32_t n_inliers;        /* RANSAC inliers of E (0 if n_good < 5) */
+    int32_t n_pose;           /* recoverPose survivors */
+    int32_t status;           /* VO_OK, or VO_ERR_FAILED when no E was found */
+    double E[9], R[9], t[3];
+} vo_pair_result;
+
+void vo_pair_params_default(vo_pair_params* p, int nfeatures);
+
+int vo_pairs_run_dev(vo_ctx* ctx, const uint8_t* d_frames, int n_frames, int w, int h, int stride,
+                     size_t frame_stride, const double* K, const vo_pair_params* params,
+                     vo_pair_result* results);
+
+/* After vo_pairs_run_dev: copy out the details of pair `pair` for parity checks (any pointer may
+ * be NULL). kp/desc are those of frame `pair` (0) and `pair+1` (1). */
+int vo_pairs_get_frame(vo_ctx* ctx, int frame, vo_keypoint* kp, uint8_t* desc, int cap, int* n);
+int vo_pairs_get_matches(vo_ctx* ctx, int pair, vo_dmatch* good, uint8_t* inlier_mask,
+                         uint8_t* pose_mask, int cap, int* n);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------
+ * When enabled, launches of the matcher kernel are bracketed with HIP events on the ctx stream;
+ * vo_prof_get returns the number of launches and their summed duration since the last reset. */
+#define VO_PROF_KNN 0
+#define VO_PROF_FAST 1
+#define VO_PROF_SOLVE 2
+#define VO_PROF_COUNT 3
+int vo_prof_enable(vo_ctx* ctx, int on);
+int vo_prof_get(vo_ctx* ctx, int which, int reset, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

@@ -558,7 +558,7 @@ static int find_essential(const float* p0, const float* p1, int n, const double*
         if (stats) stats[2] = good;
         memcpy(E, best, sizeof(best));
         if (mask) memcpy(mask, cur_mask.data(), n);
-        return good >= modelPoints ? VO_OK : VO_ERR_FAILED;
+        return VO_OK;  // cv copies the best model out even when fewer than 5 points are inliers
     }
     return VO_ERR_INVALID;
 }

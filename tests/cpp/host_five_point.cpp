@@ -1,0 +1,24 @@
+// Host build of the device five-point solver and Jacobi SVD (visual_odometry_amd/csrc/five_point.h,
+// small_linalg.h) so that their numerics can be checked against the oracle without a GPU.
+// Test-only: built by tests/test_host_solver.py into tests/cpp/libhost_solver.so.
+#include "../../visual_odometry_amd/csrc/five_point.h"
+
+struct HostScratch {
+    double* base;
+    double& operator()(int i) const { return base[i]; }
+};
+
+extern "C" int host_five_point(const double* x1, const double* x2, double* E_out) {
+    double scratch[FP_SCRATCH];
+    HostScratch s{scratch};
+    return five_point_solve(x1, x2, s, E_out);
+}
+
+extern "C" void host_decompose_essential(const double* E, double* R1, double* R2, double* t) {
+    decompose_essential(E, R1, R2, t);
+}
+
+extern "C" void host_triangulate_point(const double* P0, const double* P1, const double* x0,
+                                       const double* x1, double* X) {
+    triangulate_point(P0, P1, x0[0], x0[1], x1[0], x1[1], X);
+}

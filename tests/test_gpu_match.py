@@ -1,0 +1,124 @@
+"""GPU parity: brute-force Hamming 2-NN and the ratio/displacement filter, through the C ABI,
+against the CPU oracle.  Bit-exact bar: indices, distances, order.
+Reads like the reference's use in matcher() (src/matcher/matcher.cpp:17-38)."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_knn(a, b):
+    assert a.shape == b.shape
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (7, 5), (64, 64), (257, 1000), (2000, 2000), (2000, 1999), (3001, 777)])
+def test_knn2_random(vo, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    g, gv = vo.knn2_hamming(q, t)
+    o, ov = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+    assert np.array_equal(gv, ov)
+
+
+def test_knn2_planted_2k(vo, oracle):
+    q, t = synth.matcher_descriptors(2000)
+    g, gv = vo.knn2_hamming(q, t)
+    o, ov = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+
+
+def test_knn2_ties_keep_lower_train_index(vo, oracle):
+    # few distinct rows, many exact duplicates -> every query has tied neighbours
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    q = base[rng.integers(0, 6, 300)]
+    t = base[rng.integers(0, 6, 500)]
+    g, _ = vo.knn2_hamming(q, t)
+    o, _ = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+    assert (g["distance"][:, 0] == 0).all() and (g["trainIdx"][:, 0] < g["trainIdx"][:, 1]).all()
+
+
+@pytest.mark.parametrize("nt", [0, 1])
+def test_knn2_fewer_than_two_train_rows(vo, oracle, nt):
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (10, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    g, gv = vo.knn2_hamming(q, t)
+    o, ov = oracle.knn2_hamming(q, t)
+    assert np.array_equal(gv, ov) and (gv == nt).all()
+    assert np.array_equal(g["trainIdx"], o["trainIdx"])
+    # the reference indexes matches[k][1] unconditionally; such rows are skipped by the filter
+    kq = np.zeros(10, oracle.KP_DTYPE)
+    kt = np.zeros(max(nt, 1), oracle.KP_DTYPE)
+    assert len(vo.match_filter(g, gv, kq, kt)) == 0
+    assert len(oracle.match_filter(o, ov, kq, kt)) == 0
+
+
+def test_knn2_empty_query(vo):
+    g, gv = vo.knn2_hamming(np.zeros((0, 32), np.uint8), np.zeros((5, 32), np.uint8))
+    assert g.shape == (0, 2)
+
+
+@pytest.mark.parametrize("d", [61, 64, 16])
+def test_knn2_other_descriptor_sizes(vo, oracle, d):
+    # AKAZE's MLDB descriptors are 61 bytes (what addKeyFrame feeds matcher(),
+    # src/sfm/bundle_adjustment.cpp:41,58)
+    rng = np.random.default_rng(d)
+    q = rng.integers(0, 256, (300, d), dtype=np.uint8)
+    t = rng.integers(0, 256, (400, d), dtype=np.uint8)
+    g, _ = vo.knn2_hamming(q, t)
+    o, _ = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+
+
+def test_knn2_stress_8k(vo, oracle):
+    # BASELINE config 3 shape; the oracle takes a few seconds
+    q, t = synth.matcher_descriptors(8192)
+    g, _ = vo.knn2_hamming(q, t)
+    o, _ = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+
+
+def test_match_filter_parity(vo, oracle):
+    rng = np.random.default_rng(3)
+    n = 2000
+    q, t = synth.matcher_descriptors(n)
+    kq = np.zeros(n, oracle.KP_DTYPE)
+    kt = np.zeros(n, oracle.KP_DTYPE)
+    kq["x"] = rng.uniform(0, 1241, n).astype(np.float32)
+    kq["y"] = rng.uniform(0, 376, n).astype(np.float32)
+    kt["x"] = rng.uniform(0, 1241, n).astype(np.float32)
+    kt["y"] = rng.uniform(0, 376, n).astype(np.float32)
+    o, ov = oracle.knn2_hamming(q, t)
+    # make displacement matter: planted matches sit near their query, with some exactly at the gate
+    perm = o["trainIdx"][:, 0]
+    kt["x"][perm] = kq["x"] + rng.normal(0, 120, n).astype(np.float32)
+    kt["y"][perm] = kq["y"] + rng.normal(0, 120, n).astype(np.float32)
+    kt["x"][perm[:5]] = kq["x"][:5] + np.float32(200.0)
+    kt["y"][perm[:5]] = kq["y"][:5]
+    g, gv = vo.knn2_hamming(q, t)
+    good_g = vo.match_filter(g, gv, kq, kt, 0.7, 200.0)
+    good_o = oracle.match_filter(o, ov, kq, kt, 0.7, 200.0)
+    assert 100 < len(good_o) < n
+    assert np.array_equal(good_g, good_o)
+
+
+def test_match_filter_ratio_boundary(vo, oracle):
+    # d0 < 0.7f * d1 evaluated in float: 7 < 0.7f*10 is true in float (0.7f*10 = 7.0000002...)
+    knn = np.zeros((3, 2), oracle.DM_DTYPE)
+    knn["queryIdx"][:, 0] = knn["queryIdx"][:, 1] = np.arange(3)
+    knn["trainIdx"][:, 0] = [0, 1, 2]
+    knn["trainIdx"][:, 1] = [1, 2, 0]
+    knn["distance"][:, 0] = [7, 14, 70]
+    knn["distance"][:, 1] = [10, 20, 100]
+    kq = np.zeros(3, oracle.KP_DTYPE)
+    kt = np.zeros(3, oracle.KP_DTYPE)
+    nv = np.full(3, 2, np.int32)
+    assert np.array_equal(vo.match_filter(knn, nv, kq, kt), oracle.match_filter(knn, nv, kq, kt))

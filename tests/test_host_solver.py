@@ -1,0 +1,72 @@
+"""CPU check of the DEVICE five-point solver and Jacobi SVD: visual_odometry_amd/csrc/five_point.h
+and small_linalg.h also compile for the host, so their numerics are compared with the oracle here
+without a GPU (a CPU build of device code, built into tests/cpp/)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+K = synth.KITTI_K
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(HERE, "cpp", "libhost_solver.so")
+    src = os.path.join(HERE, "cpp", "host_five_point.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", so, src])
+    return C.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_device_five_point_matches_oracle(host, oracle):
+    rng = np.random.default_rng(1)
+    diffs = []
+    for trial in range(400):
+        p0, p1, *_ = synth.correspondences(40, seed=trial, inlier_ratio=0.7)
+        x1 = np.stack([(p0[:, 0] - K[0, 2]) / K[0, 0], (p0[:, 1] - K[1, 2]) / K[1, 1]], 1).astype(np.float64)
+        x2 = np.stack([(p1[:, 0] - K[0, 2]) / K[0, 0], (p1[:, 1] - K[1, 2]) / K[1, 1]], 1).astype(np.float64)
+        idx = rng.choice(40, 5, replace=False)
+        a = np.ascontiguousarray(x1[idx])
+        b = np.ascontiguousarray(x2[idx])
+        Eo = oracle.five_point(a, b)
+        Eh = np.zeros((10, 3, 3))
+        n = host.host_five_point(_p(a), _p(b), _p(Eh))
+        assert n == len(Eo)  # same number of real solutions
+        for E in Eh[:n]:
+            # same sign too: both complete the null space the way cv::SVD does
+            diffs.append(min(np.abs(E - F).max() for F in Eo))
+            assert np.abs([np.r_[q, 1] @ E @ np.r_[p, 1] for p, q in zip(a, b)]).max() < 1e-9
+    diffs = np.array(diffs)
+    assert np.median(diffs) < 1e-12 and np.percentile(diffs, 99) < 1e-6
+
+
+def test_device_decompose_and_triangulate_match_oracle(host, oracle):
+    rng = np.random.default_rng(2)
+    for trial in range(50):
+        R = synth.rotation(rng.normal(0, 0.1, 3))
+        t = rng.normal(0, 1, 3)
+        t /= np.linalg.norm(t)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = np.ascontiguousarray(tx @ R)
+        R1, R2, tt = np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3)
+        host.host_decompose_essential(_p(E), _p(R1), _p(R2), _p(tt))
+        o1, o2, ot = oracle.decompose_essential(E)
+        assert np.abs(R1 - o1).max() < 1e-12 and np.abs(R2 - o2).max() < 1e-12 and np.abs(tt - ot).max() < 1e-12
+        P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+        P1 = np.ascontiguousarray(np.hstack([R, t[:, None]]))
+        X = rng.uniform([-3, -2, 4], [3, 2, 20], 3)
+        x0 = np.ascontiguousarray(X[:2] / X[2])
+        Xc = R @ X + t
+        x1 = np.ascontiguousarray(Xc[:2] / Xc[2])
+        out = np.zeros(4)
+        host.host_triangulate_point(_p(P0), _p(P1), _p(x0), _p(x1), _p(out))
+        q = oracle.triangulate_points(P0, P1, x0[None], x1[None])[:, 0]
+        assert np.abs(out - q).max() < 1e-12

@@ -1,0 +1,69 @@
+"""Loader for libvo_hip.so (the C ABI declared in include/vo_hip.h).
+
+The product has no CPU fallback: if the HIP library is missing, or no HIP device is usable,
+loading / context creation raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/vo_hip.h declares
+SYMBOLS = [
+    "vo_limits_default", "vo_ctx_create", "vo_ctx_destroy", "vo_last_error", "vo_ctx_synchronize",
+    "vo_orb_params_default", "vo_fast_detect", "vo_orb_detect_compute", "vo_orb_compute",
+    "vo_knn2_hamming", "vo_match_filter", "vo_find_essential", "vo_recover_pose", "vo_triangulate",
+    "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
+    "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get",
+]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_width", C.c_int32), ("max_height", C.c_int32), ("max_features", C.c_int32),
+                ("max_points", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class PairParams(C.Structure):
+    _fields_ = [("orb", OrbParams), ("ratio", C.c_float), ("max_disp", C.c_float), ("prob", C.c_double),
+                ("threshold", C.c_double), ("dist_thresh", C.c_double), ("seed", C.c_uint64),
+                ("max_iters", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("n_kp0", C.c_int32), ("n_kp1", C.c_int32), ("n_good", C.c_int32), ("n_inliers", C.c_int32),
+                ("n_pose", C.c_int32), ("status", C.c_int32), ("E", C.c_double * 9), ("R", C.c_double * 9),
+                ("t", C.c_double * 3)]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 with the recipe in csrc/Makefile (cross-compiles)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libvo_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C visual_odometry_amd/csrc`); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.vo_last_error.restype = C.c_char_p
+        _lib.vo_last_error.argtypes = [C.c_void_p]
+        _lib.vo_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.vo_ctx_destroy.restype = None
+    return _lib

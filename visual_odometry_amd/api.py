@@ -1,0 +1,228 @@
+"""numpy-level binding of the C ABI (include/vo_hip.h): one method per entry point.
+
+This is plumbing for tests and bench.py; the host-side mirror of the reference's C++ interface
+lives in visual_odometry_amd/host/ (C++) and visual_odometry_amd/reference_api.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OrbParams, Limits, PairParams, PairResult
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")]
+)
+DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+LMEDS, RANSAC = 4, 8
+VO_OK, VO_ERR_INVALID, VO_ERR_CAPACITY, VO_ERR_DEVICE, VO_ERR_FAILED = 0, 1, 2, 3, 4
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def orb_params(nfeatures=2000, **kw):
+    p = OrbParams()
+    _lib.lib().vo_orb_params_default(C.byref(p), int(nfeatures))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def pair_params(nfeatures=2000, **kw):
+    p = PairParams()
+    _lib.lib().vo_pair_params_default(C.byref(p), int(nfeatures))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _img(gray):
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    assert gray.ndim == 2
+    return gray
+
+
+class VoContext:
+    """One vo_ctx (one HIP stream + workspace) on `device`."""
+
+    def __init__(self, device=0, **limits):
+        self.L = _lib.lib()
+        lim = Limits()
+        self.L.vo_limits_default(C.byref(lim))
+        for k, v in limits.items():
+            setattr(lim, k, v)
+        self.limits = lim
+        h = C.c_void_p()
+        rc = self.L.vo_ctx_create(int(device), C.byref(lim), C.byref(h))
+        if rc != 0:
+            raise VoError(rc, "vo_ctx_create failed (no usable HIP device? there is no CPU fallback)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vo_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise VoError(rc, self.L.vo_last_error(self.h).decode())
+        return rc
+
+    def synchronize(self):
+        self._check(self.L.vo_ctx_synchronize(self.h))
+
+    # ---- features ----------------------------------------------------------------------
+    def fast_detect(self, gray, threshold=20, nms=True, cap=None):
+        gray = _img(gray)
+        h, w = gray.shape
+        cap = w * h // 4 if cap is None else cap
+        out = np.zeros(max(cap, 1), KP_DTYPE)
+        n = C.c_int(0)
+        self._check(self.L.vo_fast_detect(self.h, _p(gray), w, h, gray.strides[0], int(threshold),
+                                          int(bool(nms)), _p(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def orb_detect_compute(self, gray, params, cap=None):
+        gray = _img(gray)
+        h, w = gray.shape
+        cap = max(2 * params.nfeatures, 64) if cap is None else cap
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self.L.vo_orb_detect_compute(self.h, _p(gray), w, h, gray.strides[0], C.byref(params),
+                                                 _p(kp), _p(desc), cap, C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def orb_compute(self, gray, params, kps):
+        gray = _img(gray)
+        h, w = gray.shape
+        kp = np.array(kps, dtype=KP_DTYPE, copy=True)
+        n = C.c_int(len(kp))
+        desc = np.zeros((max(len(kp), 1), 32), np.uint8)
+        self._check(self.L.vo_orb_compute(self.h, _p(gray), w, h, gray.strides[0], C.byref(params), _p(kp),
+                                          C.byref(n), _p(desc)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    # ---- matcher -------------------------------------------------------------------------
+    def knn2_hamming(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = q.shape[0], t.shape[0]
+        d = q.shape[1] if q.ndim == 2 and nq else (t.shape[1] if t.ndim == 2 and nt else 32)
+        out = np.zeros((nq, 2), DM_DTYPE)
+        nv = np.zeros(max(nq, 1), np.int32)
+        self._check(self.L.vo_knn2_hamming(self.h, _p(q), nq, _p(t), nt, d, _p(out), _p(nv)))
+        return out, nv[:nq]
+
+    def match_filter(self, knn, n_valid, kq, kt, ratio=0.7, max_disp=200.0):
+        knn = np.ascontiguousarray(knn, DM_DTYPE)
+        nq = knn.shape[0]
+        good = np.zeros(max(nq, 1), DM_DTYPE)
+        n = C.c_int(0)
+        kq = np.ascontiguousarray(kq, KP_DTYPE)
+        kt = np.ascontiguousarray(kt, KP_DTYPE)
+        nv = np.ascontiguousarray(n_valid, np.int32) if n_valid is not None else None
+        self._check(self.L.vo_match_filter(self.h, _p(knn), _p(nv), nq, _p(kq), _p(kt), C.c_float(ratio),
+                                           C.c_float(max_disp), _p(good), C.byref(n)))
+        return good[: n.value].copy()
+
+    # ---- sfm -----------------------------------------------------------------------------
+    def find_essential(self, p0, p1, K, method=RANSAC, prob=0.999, threshold=1.0, seed=2**64 - 1,
+                       max_iters=1000):
+        """Returns (rc, E, mask); rc is VO_OK or VO_ERR_FAILED (cv's empty-matrix case)."""
+        p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        n = p0.shape[0]
+        E = np.zeros((3, 3))
+        mask = np.zeros(max(n, 1), np.uint8)
+        rc = self.L.vo_find_essential(self.h, _p(p0), _p(p1), n, _p(K), int(method), C.c_double(prob),
+                                      C.c_double(threshold), C.c_uint64(seed & (2**64 - 1)), int(max_iters),
+                                      _p(E), _p(mask))
+        self._check(rc, allow=(VO_ERR_FAILED,))
+        return rc, E, mask[:n].copy()
+
+    def recover_pose(self, E, p0, p1, K, dist_thresh=200.0, mask=None):
+        """Returns (n_good, R, t, mask, pts4d)."""
+        E = np.ascontiguousarray(E, np.float64)
+        p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        n = p0.shape[0]
+        m = np.array(mask, np.uint8, copy=True) if mask is not None else None
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        pts = np.zeros((4, max(n, 1)))
+        if n > 0:
+            pts = np.zeros((4, n))
+        ng = C.c_int(0)
+        self._check(self.L.vo_recover_pose(self.h, _p(E), _p(p0), _p(p1), n, _p(K), C.c_double(dist_thresh),
+                                           _p(m), _p(R), _p(t), _p(pts), C.byref(ng)))
+        return ng.value, R, t, m, pts[:, :n].copy()
+
+    def triangulate(self, p0, p1, P0, P1):
+        p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        P0 = np.ascontiguousarray(P0, np.float64)
+        P1 = np.ascontiguousarray(P1, np.float64)
+        n = p0.shape[0]
+        out = np.zeros((n, 3))
+        self._check(self.L.vo_triangulate(self.h, _p(p0), _p(p1), n, _p(P0), _p(P1), _p(out)))
+        return out
+
+    def projection_matrix(self, K, pose):
+        K = np.ascontiguousarray(K, np.float64)
+        pose = np.ascontiguousarray(pose, np.float64)
+        P = np.zeros((3, 4))
+        self.L.vo_projection_matrix(_p(K), _p(pose), _p(P))
+        return P
+
+    # ---- device-resident batch -----------------------------------------------------------
+    def pairs_run_dev(self, d_ptr, n_frames, w, h, stride, frame_stride, K, params):
+        """d_ptr: integer device address of the frames. Returns a list of PairResult."""
+        K = np.ascontiguousarray(K, np.float64)
+        res = (PairResult * max(n_frames - 1, 1))()
+        self._check(self.L.vo_pairs_run_dev(self.h, C.c_void_p(d_ptr), int(n_frames), int(w), int(h), int(stride),
+                                            C.c_size_t(frame_stride), _p(K), C.byref(params), res))
+        return res
+
+    def pairs_get_frame(self, frame, cap=32768):
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self.L.vo_pairs_get_frame(self.h, int(frame), _p(kp), _p(desc), cap, C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def pairs_get_matches(self, pair, cap=32768):
+        good = np.zeros(cap, DM_DTYPE)
+        m1 = np.zeros(cap, np.uint8)
+        m2 = np.zeros(cap, np.uint8)
+        n = C.c_int(0)
+        self._check(self.L.vo_pairs_get_matches(self.h, int(pair), _p(good), _p(m1), _p(m2), cap, C.byref(n)))
+        return good[: n.value].copy(), m1[: n.value].copy(), m2[: n.value].copy()
+
+    # ---- measurement hooks ---------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self.L.vo_prof_enable(self.h, int(bool(on))))
+
+    def prof_get(self, which, reset=True):
+        n = C.c_int(0)
+        ms = C.c_double(0)
+        self._check(self.L.vo_prof_get(self.h, int(which), int(bool(reset)), C.byref(n), C.byref(ms)))
+        return n.value, ms.value

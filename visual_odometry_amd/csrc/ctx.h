@@ -1,0 +1,170 @@
+// ctx.h — internal context of libvo_hip.so: one HIP stream, grow-only device workspace,
+// pinned staging, error string.  Not part of the ABI (include/vo_hip.h is).
+#ifndef VO_CTX_H
+#define VO_CTX_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vo_hip.h"
+#include "kernels.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfSlot {
+    int launches = 0;
+    double total_ms = 0;
+};
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vo_limits lim;
+    char err[512];
+    bool prof_on = false;
+    ProfSlot prof[VO_PROF_COUNT];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // ---- feature workspace (per frame strides: geom.pyr_bytes, max_cand, kp_cap) ---------
+    DevBuf d_img;     // uploaded frames (host-pointer entry points)
+    DevBuf d_pyr;     // packed pyramid levels >= 1
+    DevBuf d_blur;    // blurred pyramid, all levels
+    DevBuf d_score;   // FAST score map, all levels
+    DevBuf d_rowcnt;  // int [frame][rows_total]
+    DevBuf d_rowofs;  // int [frame][rows_total + 1]
+    DevBuf d_lvlofs;  // int [frame][VO_ORB_MAX_LEVELS + 1]
+    DevBuf d_cand;    // Cand [frame][max_cand]
+    DevBuf d_sel;     // Cand [frame][kp_cap]: keypoints selected on the host
+    DevBuf d_coef;    // resize coefficient tables
+    DevBuf d_geom;    // PyrGeom
+    DevBuf d_kp;      // vo_keypoint [frame][kp_cap]
+    DevBuf d_desc;    // uint8 [frame][kp_cap][32]
+    DevBuf d_nkp;     // int [frame] (+1 spare)
+    PinnedBuf h_lvlofs, h_cand, h_sel, h_nkp, h_misc;
+    int max_cand = 65536;
+    int kp_cap = 0;
+    int feat_frames = 0;
+
+    PyrGeom geom;  // host copy of d_geom
+    int quota[VO_ORB_MAX_LEVELS];
+    int geom_w = 0, geom_h = 0, geom_levels = 0, geom_nfeatures = -1;
+    float geom_scale = 0;
+    std::vector<uint32_t> coef_host;
+    std::vector<size_t> coef_x, coef_y;  // per level offsets into d_coef (uint32 units)
+
+    // ---- matcher workspace ---------------------------------------------------------------
+    DevBuf d_q, d_t;    // descriptor uploads (host-pointer entry points)
+    DevBuf d_part;      // uint2 [pair][split][nq_cap]
+    DevBuf d_knn;       // uint2 [pair][nq_cap]
+    DevBuf d_good;      // GoodMatch [pair][nq_cap]
+    DevBuf d_ngood;     // int [pair]
+    DevBuf d_p0, d_p1;  // float2 [pair][nq_cap]
+    DevBuf d_kq, d_kt;  // keypoint uploads (host-pointer match filter)
+    PinnedBuf h_knn, h_good;
+
+    // ---- geometry workspace ----------------------------------------------------------------
+    DevBuf d_samples;  // uint16 [max_points + 1][samples_iters][5] (+ pad)
+    int samples_max_n = 0, samples_iters = 0;
+    uint64_t samples_seed = 0;
+    DevBuf d_x1, d_x2;   // double2 [pair][n_cap]: K-normalised points
+    DevBuf d_models;     // double [pair][H][10][9]
+    DevBuf d_nmodels;    // int [pair][H]
+    DevBuf d_counts;     // int [pair][H][10] inlier counts (RANSAC) / float medians (LMedS)
+    DevBuf d_state;      // EstState [pair]
+    DevBuf d_mask;       // uint8 [pair][n_cap]
+    DevBuf d_q4;         // double [pair][4][4][n_cap]: triangulations of the 4 candidates
+    DevBuf d_cmask;      // uint8 [pair][4][n_cap]
+    DevBuf d_pose;       // PoseState [pair]
+    DevBuf d_pmask;      // uint8 [pair][n_cap]: recoverPose mask
+    DevBuf d_pts4;       // double [pair][4][n_cap]: winner's points
+    DevBuf d_fp0, d_fp1; // float2 uploads (host-pointer entry points)
+    DevBuf d_cam;        // CamK [pair]
+    DevBuf d_proj;       // double[24]: P0, P1 (vo_triangulate)
+    PinnedBuf h_state, h_pose, h_mask, h_pts;
+
+    // ---- vo_pairs_run_dev bookkeeping --------------------------------------------------------
+    int pipe_frames = 0, pipe_ncap = 0;
+    std::vector<int> pipe_nkp;
+    std::vector<int> pipe_ngood;
+
+    int fail(int code, const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, sizeof(err), fmt, ap);
+        va_end(ap);
+        return code;
+    }
+};
+
+#define VO_HIP(ctx, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return (ctx)->fail(VO_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr,                \
+                               hipGetErrorString(e__), __FILE__, __LINE__);                  \
+    } while (0)
+
+#define VO_TRY(expr)                    \
+    do {                                \
+        int rc__ = (expr);              \
+        if (rc__ != VO_OK) return rc__; \
+    } while (0)
+
+int vo_ensure(vo_ctx* ctx, DevBuf& b, size_t bytes);
+int vo_ensure_pinned(vo_ctx* ctx, PinnedBuf& b, size_t bytes);
+int vo_check_launch(vo_ctx* ctx, const char* what);
+
+// features (vo_features.cpp)
+int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);
+int feat_detect(vo_ctx* c, const FrameSrc& src, int nframes, int fast_threshold, int border, int nms,
+                int harris);
+int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out);
+int feat_describe(vo_ctx* c, const FrameSrc& src, int nframes, int max_n, bool angles);
+
+// geometry (vo_geometry.cpp)
+struct EstArgs;
+int geom_prepare(vo_ctx* c, int npairs, int n_cap, uint64_t seed, int max_iters);
+int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0, const float2* d_p1,
+                            const int* d_n, int n_host, const double* K, int method, double prob,
+                            double threshold, int max_iters);
+int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, size_t e_stride,
+                          const float2* d_p0, const float2* d_p1, const int* d_n, int n_host,
+                          const double* K, double dist_thresh, bool use_mask);
+
+// profiling bracket (no-ops unless vo_prof_enable(ctx, 1))
+struct ProfScope {
+    vo_ctx* c;
+    int which;
+    bool on;
+    ProfScope(vo_ctx* ctx, int w) : c(ctx), which(w), on(ctx->prof_on) {
+        if (on) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->prof[which].launches++;
+        c->prof[which].total_ms += ms;
+    }
+};
+
+#endif

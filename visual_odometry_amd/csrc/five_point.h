@@ -1,0 +1,462 @@
+// five_point.h — Nister's five-point relative-pose solver, one hypothesis per GPU lane (fp64).
+//
+// Same mathematics as cv's EMEstimatorCallback::runKernel (calib3d/src/five-point.cpp; SURVEY.md
+// A.5): null space of the 5x9 epipolar system, the ten cubic constraints det(E) = 0 and
+// 2 E E^T E - tr(E E^T) E = 0 in Nister's monomial order, elimination of the ten leading
+// monomials, the 3x3 polynomial matrix B(z), det B(z) = 0 (degree 10), back-substitution.
+// The numerical methods are chosen for a lane, not copied from the CPU path:
+//   * null space by Householder QR of the 9x5 transpose (static loops, registers),
+//   * constraint expansion with compile-time monomial tables (registers),
+//   * Gauss-Jordan with partial pivoting on the 10x20 matrix held in a per-lane LDS column
+//     (dynamic row indices are free in LDS, impossible in registers),
+//   * real roots only, by bracketing between the roots of successive derivatives and
+//     safeguarded Newton (no complex arithmetic, no iteration over the complex roots cv's
+//     Durand-Kerner also finds and then discards).
+// `S` is the per-lane scratch accessor: S(i) is element i of FP_SCRATCH doubles.
+// The header compiles for the host too (tests/host_five_point.cpp checks it against the oracle
+// without a GPU).
+#ifndef VO_FIVE_POINT_H
+#define VO_FIVE_POINT_H
+
+#include "small_linalg.h"
+
+#define FP_SCRATCH 236  // 10x20 constraint matrix + 4x9 null-space basis
+
+namespace fp_detail {
+
+VO_HD void mul_ll_acc(const double* a, const double* b, double* q, double sgn) {
+    constexpr int LL[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[LL[i][j]] += sgn * (a[i] * b[j]);
+}
+
+VO_HD void mul_ql_acc(const double* q, const double* l, double* c, double sgn) {
+    constexpr int QL[10][4] = {{0, 2, 4, 5},     {3, 1, 6, 7},    {10, 13, 16, 17}, {2, 3, 8, 9},
+                               {4, 8, 10, 11},   {8, 6, 13, 14},  {5, 9, 11, 12},   {9, 7, 14, 15},
+                               {11, 14, 17, 18}, {12, 15, 18, 19}};
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[QL[i][j]] += sgn * (q[i] * l[j]);
+}
+
+constexpr double falling(int n, int k) {  // n! / (n-k)!
+    double r = 1;
+    for (int i = 0; i < k; i++) r *= (double)(n - i);
+    return r;
+}
+
+template <int D>
+VO_HD void horner(const double (&a)[D + 1], double x, double& f, double& df) {
+    f = a[D];
+    df = 0;
+#pragma unroll
+    for (int i = D - 1; i >= 0; i--) {
+        df = df * x + f;
+        f = f * x + a[i];
+    }
+}
+
+// root of a (degree D) inside [lo, hi] given a sign change; safeguarded Newton / bisection
+template <int D>
+VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double flo) {
+    double xl, xh;
+    if (flo < 0) {
+        xl = lo;
+        xh = hi;
+    } else {
+        xl = hi;
+        xh = lo;
+    }
+    double rts = 0.5 * (lo + hi);
+    double dxold = fabs(hi - lo), dx = dxold, f, df;
+    horner<D>(a, rts, f, df);
+    for (int it = 0; it < 200; it++) {
+        if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+            dxold = dx;
+            dx = 0.5 * (xh - xl);
+            rts = xl + dx;
+            if (xl == rts) break;
+        } else {
+            dxold = dx;
+            dx = f / df;
+            const double temp = rts;
+            rts -= dx;
+            if (temp == rts) break;
+        }
+        if (fabs(dx) <= 4e-16 * fabs(rts)) break;
+        horner<D>(a, rts, f, df);
+        if (f < 0) xl = rts;
+        else xh = rts;
+    }
+    return rts;
+}
+
+// Real roots of the (10-D)-th derivative of c (degree D), bracketed by the roots of the next
+// derivative, which are S(prev..prev+nprev) in ascending order.  Writes S(cur..), returns count.
+template <int D, class S>
+VO_HD int level_roots(const double (&c)[11], double bound, int nprev, const S& s, int prev, int cur) {
+    double a[D + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) a[i] = c[i + (10 - D)] * falling(i + (10 - D), 10 - D);
+    int ncur = 0;
+    double lo = -bound, flo, d;
+    horner<D>(a, lo, flo, d);
+    for (int j = 0; j <= nprev; j++) {
+        const double hi = j < nprev ? s(prev + j) : bound;
+        double fhi;
+        horner<D>(a, hi, fhi, d);
+        if ((flo < 0) != (fhi < 0)) {
+            s(cur + ncur) = bracket_root<D>(a, lo, hi, flo);
+            ncur++;
+        }
+        lo = hi;
+        flo = fhi;
+    }
+    return ncur;
+}
+
+}  // namespace fp_detail
+
+// x1, x2: five K-normalised correspondences (x, y interleaved), x2^T E x1 = 0.
+// E_out: up to 10 models, 9 doubles each (row-major, unit Frobenius norm), ordered by the root z.
+template <class S>
+VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, double* E_out) {
+    using namespace fp_detail;
+    // ---- null space of Q (5x9) by Householder QR of A = Q^T (9x5) ------------------------------
+    {
+        double A[9][5], beta[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const double u1 = x1[2 * j], v1 = x1[2 * j + 1], u2 = x2[2 * j], v2 = x2[2 * j + 1];
+            A[0][j] = u2 * u1; A[1][j] = u2 * v1; A[2][j] = u2;
+            A[3][j] = v2 * u1; A[4][j] = v2 * v1; A[5][j] = v2;
+            A[6][j] = u1;      A[7][j] = v1;      A[8][j] = 1.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            double nrm2 = 0;
+#pragma unroll
+            for (int i = k; i < 9; i++) nrm2 += A[i][k] * A[i][k];
+            const double alpha = A[k][k] >= 0 ? -sqrt(nrm2) : sqrt(nrm2);
+            A[k][k] -= alpha;
+            double vn2 = 0;
+#pragma unroll
+            for (int i = k; i < 9; i++) vn2 += A[i][k] * A[i][k];
+            beta[k] = vn2 > 0 ? 2.0 / vn2 : 0.0;
+#pragma unroll
+            for (int j = k + 1; j < 5; j++) {
+                double d = 0;
+#pragma unroll
+                for (int i = k; i < 9; i++) d += A[i][k] * A[i][j];
+                d *= beta[k];
+#pragma unroll
+                for (int i = k; i < 9; i++) A[i][j] -= d * A[i][k];
+            }
+        }
+        // orthonormal basis of the row space of Q: the first five columns of the Householder Q
+        double basis[9][9];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) basis[j][i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 4; k >= 0; k--) {
+                double d = 0;
+#pragma unroll
+                for (int i = k; i < 9; i++) d += A[i][k] * basis[j][i];
+                d *= beta[k];
+#pragma unroll
+                for (int i = k; i < 9; i++) basis[j][i] -= d * A[i][k];
+            }
+        }
+        // The null-space basis fixes the (x, y, z) parametrisation and with it the conditioning of
+        // everything downstream, so it is completed the way cv::SVD(FULL_UV) completes it: fixed
+        // pseudo-random +-1/9 vectors (cv::RNG(0x12345678), bit 8 of successive outputs),
+        // orthogonalised against all earlier vectors in two passes.  The result depends on the row
+        // space only, not on which orthonormal basis of it is used.
+        constexpr int SGN[36] = {0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1,
+                                 1, 0, 0, 0, 1, 1, 0, 1, 1, 1, 0, 0, 1, 0, 1, 1, 1, 0};
+#pragma unroll
+        for (int i = 5; i < 9; i++) {
+            const double val0 = 1. / 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) basis[i][k] = SGN[9 * (i - 5) + k] ? val0 : -val0;
+            double sd = 0;
+#pragma unroll
+            for (int iter = 0; iter < 2; iter++) {
+#pragma unroll
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) sd += basis[i][k] * basis[j][k];
+                    double asum = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        const double t = basis[i][k] - sd * basis[j][k];
+                        basis[i][k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > DBL_EPSILON * 10 * 100 ? 1 / asum : 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) basis[i][k] *= asum;
+                }
+                sd = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) sd += basis[i][k] * basis[i][k];
+                sd = sqrt(sd);
+            }
+            const double sc = sd > DBL_MIN ? 1 / sd : 0.;
+#pragma unroll
+            for (int k = 0; k < 9; k++) basis[i][k] *= sc;
+#pragma unroll
+            for (int k = 0; k < 9; k++) s(200 + 9 * (i - 5) + k) = basis[i][k];
+        }
+    }
+    // ---- ten cubic constraints -> 10x20 matrix in S (row r at 20 r) -----------------------------
+    {
+        double e[9][4];  // entry (r,c) of E(x,y,z) = x N0 + y N1 + z N2 + N3
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[i][k] = s(200 + 9 * k + i);
+        {  // det(E)
+            double cub[20];
+#pragma unroll
+            for (int i = 0; i < 20; i++) cub[i] = 0;
+            double m[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) m[i] = 0;
+            mul_ll_acc(e[4], e[8], m, 1.0);
+            mul_ll_acc(e[5], e[7], m, -1.0);
+            mul_ql_acc(m, e[0], cub, 1.0);
+#pragma unroll
+            for (int i = 0; i < 10; i++) m[i] = 0;
+            mul_ll_acc(e[3], e[8], m, 1.0);
+            mul_ll_acc(e[5], e[6], m, -1.0);
+            mul_ql_acc(m, e[1], cub, -1.0);
+#pragma unroll
+            for (int i = 0; i < 10; i++) m[i] = 0;
+            mul_ll_acc(e[3], e[7], m, 1.0);
+            mul_ll_acc(e[4], e[6], m, -1.0);
+            mul_ql_acc(m, e[2], cub, 1.0);
+#pragma unroll
+            for (int i = 0; i < 20; i++) s(i) = cub[i];
+        }
+        // L = E E^T - 1/2 tr(E E^T) I (symmetric: 00 01 02 11 12 22)
+        double L[6][10];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int i = 0; i < 10; i++) L[a][i] = 0;
+        constexpr int SI[6] = {0, 0, 0, 1, 1, 2}, SJ[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) mul_ll_acc(e[3 * SI[a] + k], e[3 * SJ[a] + k], L[a], 1.0);
+        {
+            double tr[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) tr[i] = 0.5 * (L[0][i] + L[3][i] + L[5][i]);
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                L[0][i] -= tr[i];
+                L[3][i] -= tr[i];
+                L[5][i] -= tr[i];
+            }
+        }
+        constexpr int SYM[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double cub[20];
+#pragma unroll
+                for (int q = 0; q < 20; q++) cub[q] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) mul_ql_acc(L[SYM[i][k]], e[3 * k + j], cub, 1.0);
+#pragma unroll
+                for (int q = 0; q < 20; q++) s(20 * (1 + 3 * i + j) + q) = cub[q];
+            }
+    }
+    // ---- Gauss-Jordan on the first ten columns, partial pivoting ---------------------------------
+    // Only rows 4..9 of the reduced right-hand block are used afterwards, so finished rows 0..3
+    // are not updated any further.
+    for (int col = 0; col < 10; col++) {
+        int piv = col;
+        double best = fabs(s(20 * col + col));
+        for (int r = col + 1; r < 10; r++) {
+            const double v = fabs(s(20 * r + col));
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        if (!(best > 1e-300)) return 0;
+        double prow[20];
+        const double inv = 1.0 / s(20 * piv + col);
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            const double pv = s(20 * piv + k);
+            if (piv != col) s(20 * piv + k) = s(20 * col + k);
+            prow[k] = pv * inv;
+            s(20 * col + k) = prow[k];
+        }
+        for (int r = (col < 4 ? col + 1 : 4); r < 10; r++) {
+            if (r == col) continue;
+            const double f = s(20 * r + col);
+#pragma unroll
+            for (int k = 0; k < 20; k++)
+                if (k > col) s(20 * r + k) -= f * prow[k];
+        }
+    }
+    // ---- B(z): rows e - z f, g - z h, i - z j; coefficients lowest degree first ------------------
+    double c[11];
+    {
+        double B[3][3][5];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double r1[10], r2[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                r1[k] = s(20 * (4 + 2 * i) + 10 + k);
+                r2[k] = s(20 * (5 + 2 * i) + 10 + k);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++) {
+                B[i][blk][3] = -r2[3 * blk + 0];
+                B[i][blk][2] = r1[3 * blk + 0] - r2[3 * blk + 1];
+                B[i][blk][1] = r1[3 * blk + 1] - r2[3 * blk + 2];
+                B[i][blk][0] = r1[3 * blk + 2];
+                B[i][blk][4] = 0;
+            }
+            B[i][2][4] = -r2[6];
+            B[i][2][3] = r1[6] - r2[7];
+            B[i][2][2] = r1[7] - r2[8];
+            B[i][2][1] = r1[8] - r2[9];
+            B[i][2][0] = r1[9];
+        }
+        // park B for the back-substitution: S(20 + 15 i + 5 j + k)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) s(20 + 15 * i + 5 * j + k) = B[i][j][k];
+        // det B(z), degree 10
+#pragma unroll
+        for (int k = 0; k <= 10; k++) c[k] = 0;
+        // cofactors along row 0: columns (1,2), (0,2), (0,1) of rows 1,2
+        constexpr int CA[3] = {1, 0, 0}, CB[3] = {2, 2, 1};
+        constexpr int DEG[3] = {3, 3, 4};
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            double m[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) m[k] = 0;
+#pragma unroll
+            for (int p = 0; p <= DEG[CA[t]]; p++)
+#pragma unroll
+                for (int q = 0; q <= DEG[CB[t]]; q++)
+                    m[p + q] += B[1][CA[t]][p] * B[2][CB[t]][q] - B[1][CB[t]][q] * B[2][CA[t]][p];
+            const double sg = (t == 1) ? -1.0 : 1.0;
+#pragma unroll
+            for (int p = 0; p <= DEG[t]; p++)
+#pragma unroll
+                for (int q = 0; q <= DEG[CA[t]] + DEG[CB[t]]; q++) c[p + q] += sg * (B[0][t][p] * m[q]);
+        }
+    }
+    // ---- real roots of c ---------------------------------------------------------------------
+    int nroots;
+    {
+        double cmax = 0;
+#pragma unroll
+        for (int k = 0; k <= 10; k++) cmax = fmax(cmax, fabs(c[k]));
+        if (!(cmax > 0) || !(fabs(c[10]) > 0)) return 0;
+        const double sc = 1.0 / cmax;
+        double lead = fabs(c[10] * sc), bmax = 0;
+#pragma unroll
+        for (int k = 0; k <= 10; k++) c[k] *= sc;
+#pragma unroll
+        for (int k = 0; k < 10; k++) bmax = fmax(bmax, fabs(c[k]));
+        const double bound = 1.0 + bmax / lead;  // Cauchy bound
+        if (!(bound < 1e300)) return 0;
+        // roots of successive derivatives; two ping-pong arrays S(0..9) / S(10..19)
+        int n = level_roots<1>(c, bound, 0, s, 10, 0);
+        n = level_roots<2>(c, bound, n, s, 0, 10);
+        n = level_roots<3>(c, bound, n, s, 10, 0);
+        n = level_roots<4>(c, bound, n, s, 0, 10);
+        n = level_roots<5>(c, bound, n, s, 10, 0);
+        n = level_roots<6>(c, bound, n, s, 0, 10);
+        n = level_roots<7>(c, bound, n, s, 10, 0);
+        n = level_roots<8>(c, bound, n, s, 0, 10);
+        n = level_roots<9>(c, bound, n, s, 10, 0);
+        nroots = level_roots<10>(c, bound, n, s, 0, 10);  // roots at S(10..)
+    }
+    // ---- back-substitution ---------------------------------------------------------------------
+    int count = 0;
+    for (int i = 0; i < nroots; i++) {
+        const double z1 = s(10 + i);
+        const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+        double bz[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int o = 20 + 15 * j;
+            bz[j][0] = s(o + 3) * z3 + s(o + 2) * z2 + s(o + 1) * z1 + s(o + 0);
+            bz[j][1] = s(o + 8) * z3 + s(o + 7) * z2 + s(o + 6) * z1 + s(o + 5);
+            bz[j][2] = s(o + 14) * z4 + s(o + 13) * z3 + s(o + 12) * z2 + s(o + 11) * z1 + s(o + 10);
+        }
+        // null vector of Bz: the largest of the three row cross products
+        double best[3] = {0, 0, 0}, bn = -1;
+        constexpr int PA[3] = {0, 0, 1}, PB[3] = {1, 2, 2};
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const double* a = bz[PA[t]];
+            const double* b = bz[PB[t]];
+            const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2],
+                         cz = a[0] * b[1] - a[1] * b[0];
+            const double n2 = cx * cx + cy * cy + cz * cz;
+            if (n2 > bn) {
+                bn = n2;
+                best[0] = cx;
+                best[1] = cy;
+                best[2] = cz;
+            }
+        }
+        if (!(bn > 0)) continue;
+        const double invn = 1.0 / sqrt(bn);
+        if (fabs(best[2] * invn) < 1e-10) continue;
+        const double xs = best[0] / best[2], ys = best[1] / best[2];
+        double Ev[9], nrm = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            Ev[k] = s(200 + k) * xs + s(209 + k) * ys + s(218 + k) * z1 + s(227 + k);
+            nrm += Ev[k] * Ev[k];
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0)) continue;
+#pragma unroll
+        for (int k = 0; k < 9; k++) E_out[9 * count + k] = Ev[k] / nrm;
+        count++;
+    }
+    return count;
+}
+
+// cv's EMEstimatorCallback::computeError for one point (Sampson distance, rounded to float)
+VO_HD float sampson_error(const double* E, double a1, double b1, double a2, double b2) {
+    const double Ex0 = E[0] * a1 + E[1] * b1 + E[2] * 1.0;
+    const double Ex1 = E[3] * a1 + E[4] * b1 + E[5] * 1.0;
+    const double Ex2 = E[6] * a1 + E[7] * b1 + E[8] * 1.0;
+    const double Et0 = E[0] * a2 + E[3] * b2 + E[6] * 1.0;
+    const double Et1 = E[1] * a2 + E[4] * b2 + E[7] * 1.0;
+    const double x2tEx1 = a2 * Ex0 + b2 * Ex1 + 1.0 * Ex2;
+    const double a = Ex0 * Ex0;
+    const double b = Ex1 * Ex1;
+    const double c = Et0 * Et0;
+    const double d = Et1 * Et1;
+    return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+}
+
+#endif

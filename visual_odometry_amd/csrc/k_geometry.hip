@@ -1,0 +1,538 @@
+// k_geometry.hip — gfx950 kernels for cv::findEssentialMat (RANSAC / LMedS), cv::recoverPose and
+// cv::triangulatePoints, all in fp64.
+//
+//   k_solve5        one 5-point hypothesis per lane; the 10x20 elimination matrix lives in a
+//                   per-lane LDS column (120 KB per 64-lane block, one block per CU)
+//   k_score         one wave per hypothesis: Sampson error of every point against its <= 10 models,
+//                   inlier counts by wave ballot + popcount
+//   k_replay        one wave per pair: replays cv's sequential acceptance rule (strictly more
+//                   inliers wins, the iteration cap shrinks) over the counts, so the result is the
+//                   one the sequential CPU loop reaches
+//   k_lmeds_*       per-model median of the float errors by bitwise selection in LDS; arg-min
+//   k_est_finish    inlier mask of the winning model
+//   k_pose_*        decomposeEssentialMat, 4 x N DLT triangulations (4x4 Jacobi SVD per point),
+//                   cheirality masks, winner selection
+// Reference call sites: src/matcher/matcher.cpp:42, src/visual_odometry/vo_pose.h:14,19,
+// src/sfm/triangulation.cpp:64.
+#include "kernels.h"
+#include "geom_types.h"
+#include "five_point.h"
+
+namespace {
+
+struct LaneScratch {
+    double* base;  // lds + lane; element i at base[64 i]
+    __device__ __forceinline__ double& operator()(int i) const { return base[i * 64]; }
+};
+
+__device__ __forceinline__ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.);
+    p = fmin(p, 1.);
+    ep = fmax(ep, 0.);
+    ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : __double2int_rn(num / denom);
+}
+
+}  // namespace
+
+__global__ void k_est_init(EstState* __restrict__ st, const int* __restrict__ d_n, int n_host, int n_cap,
+                           int niters, float thr_f, int npairs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    EstState s;
+    int n = d_n ? d_n[p] : n_host;
+    n = min(n, n_cap);
+    s.n = n;
+    s.niters = n < 5 ? 0 : (n == 5 ? 1 : niters);
+    s.best_count = 0;
+    s.best_h = -1;
+    s.best_m = 0;
+    s.next_h = 0;
+    s.status = VO_ERR_FAILED;
+    s.n_inliers = 0;
+    s.thr_f = thr_f;
+    s.best_median = DBL_MAX;
+    for (int i = 0; i < 9; i++) s.E[i] = 0;
+    st[p] = s;
+}
+
+// K-normalised double coordinates: x = (u - cx) / fx, y = (v - cy) / fy
+__global__ __launch_bounds__(256) void k_normalize(const float2* __restrict__ p0, const float2* __restrict__ p1,
+                                                   const CamK* __restrict__ cam, const EstState* __restrict__ st,
+                                                   const int* __restrict__ d_n, int n_host, int n_cap,
+                                                   double2* __restrict__ x1, double2* __restrict__ x2) {
+    const int pair = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int n = st ? st[pair].n : (d_n ? d_n[pair] : n_host);
+    n = min(n, n_cap);
+    if (i >= n) return;
+    const CamK k = cam[pair];
+    const size_t o = (size_t)pair * n_cap + i;
+    const float2 a = p0[o], b = p1[o];
+    x1[o] = make_double2(((double)a.x - k.cx) / k.fx, ((double)a.y - k.cy) / k.fy);
+    x2[o] = make_double2(((double)b.x - k.cx) / k.fx, ((double)b.y - k.cy) / k.fy);
+}
+
+__global__ __launch_bounds__(64) void k_solve5(int h0, int h1, const EstState* __restrict__ st,
+                                               const uint16_t* __restrict__ samples, int samples_iters,
+                                               const double2* __restrict__ x1, const double2* __restrict__ x2,
+                                               int n_cap, double* __restrict__ models, int* __restrict__ nmodels,
+                                               int H) {
+    __shared__ double lds[FP_SCRATCH * 64];
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int hb = h0 + blockIdx.x * 64;
+    const int cap = min(h1, st[pair].niters);
+    if (hb >= cap) return;
+    const int h = hb + lane;
+    if (h >= cap) return;
+    const int n = st[pair].n;
+    const uint16_t* sidx = samples + ((size_t)n * samples_iters + h) * 5;
+    double a[10], b[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int id = sidx[k];
+        const double2 u = x1[(size_t)pair * n_cap + id], v = x2[(size_t)pair * n_cap + id];
+        a[2 * k] = u.x;
+        a[2 * k + 1] = u.y;
+        b[2 * k] = v.x;
+        b[2 * k + 1] = v.y;
+    }
+    LaneScratch s{lds + lane};
+    const size_t slot = (size_t)pair * H + h;
+    nmodels[slot] = five_point_solve(a, b, s, models + slot * 90);
+}
+
+// One wave per hypothesis; its models are staged in LDS, every point is loaded once.
+__global__ __launch_bounds__(256) void k_score(int h0, int h1, const EstState* __restrict__ st,
+                                               const double2* __restrict__ x1, const double2* __restrict__ x2,
+                                               int n_cap, const double* __restrict__ models,
+                                               const int* __restrict__ nmodels, int* __restrict__ counts, int H) {
+    __shared__ double Es[4][90];
+    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = h0 + blockIdx.x * 4 + wv;
+    const EstState& s = st[pair];
+    if (h >= min(h1, s.niters)) return;
+    const size_t slot = (size_t)pair * H + h;
+    const int nm = nmodels[slot];
+    for (int i = lane; i < nm * 9; i += 64) Es[wv][i] = models[slot * 90 + i];
+    __builtin_amdgcn_wave_barrier();
+    const int n = s.n;
+    const float thr = s.thr_f;
+    int cnt[10];
+#pragma unroll
+    for (int m = 0; m < 10; m++) cnt[m] = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = i < n;
+        const double2 u = ok ? x1[(size_t)pair * n_cap + i] : make_double2(0, 0);
+        const double2 v = ok ? x2[(size_t)pair * n_cap + i] : make_double2(0, 0);
+#pragma unroll
+        for (int m = 0; m < 10; m++) {
+            if (m < nm) {
+                const float err = sampson_error(&Es[wv][9 * m], u.x, u.y, v.x, v.y);
+                cnt[m] += __popcll(__ballot(ok && err <= thr));
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < 10; m++)
+            if (m < nm) counts[slot * 10 + m] = cnt[m];
+    }
+}
+
+// cv's RANSAC acceptance loop over hypotheses [h0, h1): a model replaces the best one iff it has
+// strictly more inliers (and more than 4); every acceptance shrinks the iteration cap.
+__global__ __launch_bounds__(64) void k_replay(int h0, int h1, EstState* __restrict__ st,
+                                               const int* __restrict__ nmodels, const int* __restrict__ counts,
+                                               int H, double prob) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    EstState& s = st[pair];
+    int niters = s.niters, best = s.best_count, best_h = s.best_h, best_m = s.best_m;
+    const int n = s.n;
+    for (int base = max(h0, s.next_h); base < min(h1, niters); base += 64) {
+        const int h = base + lane;
+        int v = 0, vm = 0;
+        if (h < min(h1, niters)) {
+            const size_t slot = (size_t)pair * H + h;
+            const int nm = nmodels[slot];
+            for (int m = 0; m < nm; m++) {
+                const int c = counts[slot * 10 + m];
+                if (c > v) {
+                    v = c;
+                    vm = m;
+                }
+            }
+        }
+        // exclusive prefix maximum over lower lanes, seeded with the running best and cv's floor of 4
+        int pm = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pm, o);
+            if (lane >= o) pm = max(pm, t);
+        }
+        int ex = __shfl_up(pm, 1);
+        if (lane == 0) ex = 0;
+        ex = max(ex, max(best, 4));
+        unsigned long long rec = __ballot(v > ex);
+        while (rec) {
+            const int bpos = __ffsll((long long)rec) - 1;
+            rec &= rec - 1;
+            if (base + bpos >= niters) {
+                rec = 0;
+                break;
+            }
+            best = __shfl(v, bpos);
+            best_m = __shfl(vm, bpos);
+            best_h = base + bpos;
+            niters = ransac_update_num_iters(prob, (double)(n - best) / n, 5, niters);
+        }
+    }
+    if (lane == 0) {
+        s.niters = niters;
+        s.best_count = best;
+        s.best_h = best_h;
+        s.best_m = best_m;
+        s.next_h = h1;
+    }
+}
+
+// LMedS: median of the float Sampson errors of one model, by bitwise selection on the error bit
+// patterns held in LDS (non-negative floats order like unsigned integers).
+__global__ __launch_bounds__(256) void k_lmeds_medians(const EstState* __restrict__ st,
+                                                       const double2* __restrict__ x1,
+                                                       const double2* __restrict__ x2, int n_cap,
+                                                       const double* __restrict__ models,
+                                                       const int* __restrict__ nmodels,
+                                                       double* __restrict__ medians, int H) {
+    extern __shared__ uint32_t errs[];  // 4 waves x n_cap
+    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int idx = blockIdx.x * 4 + wv;
+    const int h = idx / 10, m = idx % 10;
+    const EstState& s = st[pair];
+    if (h >= s.niters) return;
+    const size_t slot = (size_t)pair * H + h;
+    if (m >= nmodels[slot]) return;
+    const int n = s.n;
+    uint32_t* e = errs + (size_t)wv * n_cap;
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) E[k] = models[slot * 90 + 9 * m + k];
+    for (int i = lane; i < n; i += 64) {
+        const double2 u = x1[(size_t)pair * n_cap + i], v = x2[(size_t)pair * n_cap + i];
+        e[i] = __float_as_uint(sampson_error(E, u.x, u.y, v.x, v.y));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // k-th smallest (0-based) for k = n/2 and, for even n, n/2 - 1
+    const int kb = n / 2, ka = (n & 1) ? kb : kb - 1;
+    uint32_t ra = 0, rb = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
+        int na = 0, nb = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t v = i < n ? e[i] : 0xffffffffu;
+            na += __popcll(__ballot(v < ca));
+            nb += __popcll(__ballot(v < cb));
+        }
+        if (na <= ka) ra = ca;
+        if (nb <= kb) rb = cb;
+    }
+    if (lane == 0) {
+        const float fa = __uint_as_float(ra), fb = __uint_as_float(rb);
+        medians[slot * 10 + m] = (n & 1) ? (double)fb : (double)(fa + fb) * 0.5;
+    }
+}
+
+// first strictly smaller median wins (hypotheses, then models, in order); sets the inlier threshold
+__global__ __launch_bounds__(64) void k_lmeds_select(EstState* __restrict__ st, const int* __restrict__ nmodels,
+                                                     const double* __restrict__ medians, int H) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    EstState& s = st[pair];
+    if (s.n == 5) {
+        // cv solves once on all five points and marks them all inliers; the first model is kept
+        if (lane == 0) {
+            s.best_h = nmodels[(size_t)pair * H] > 0 ? 0 : -1;
+            s.best_m = 0;
+            s.thr_f = __builtin_inff();
+        }
+        return;
+    }
+    const int total = s.niters * 10;
+    double best = DBL_MAX;
+    int bi = 0x7fffffff;
+    for (int idx = lane; idx < total; idx += 64) {
+        const int h = idx / 10, m = idx % 10;
+        const size_t slot = (size_t)pair * H + h;
+        if (m < nmodels[slot]) {
+            const double v = medians[slot * 10 + m];
+            if (v < best) {
+                best = v;
+                bi = idx;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob < best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        if (best < DBL_MAX) {
+            s.best_h = bi / 10;
+            s.best_m = bi % 10;
+            s.best_median = best;
+            double sigma = 2.5 * 1.4826 * (1 + 5. / (s.n - 5)) * sqrt(best);
+            sigma = fmax(sigma, 0.001);
+            s.thr_f = (float)(sigma * sigma);
+        } else {
+            s.best_h = -1;
+        }
+    }
+}
+
+// inlier mask + count of the winning model, E into the state
+__global__ __launch_bounds__(256) void k_est_finish(EstState* __restrict__ st, const double2* __restrict__ x1,
+                                                    const double2* __restrict__ x2, int n_cap,
+                                                    const double* __restrict__ models, uint8_t* __restrict__ mask,
+                                                    int H) {
+    __shared__ int total;
+    const int pair = blockIdx.x;
+    EstState& s = st[pair];
+    const int n = s.n;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint8_t* mk = mask + (size_t)pair * n_cap;
+    if (s.best_h < 0) {
+        for (int i = threadIdx.x; i < n; i += 256) mk[i] = 0;
+        return;
+    }
+    double E[9];
+    const size_t slot = (size_t)pair * H + s.best_h;
+#pragma unroll
+    for (int k = 0; k < 9; k++) E[k] = models[slot * 90 + 9 * s.best_m + k];
+    const float thr = s.thr_f;
+    int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool inl = false;
+        if (i < n) {
+            const double2 u = x1[(size_t)pair * n_cap + i], v = x2[(size_t)pair * n_cap + i];
+            inl = sampson_error(E, u.x, u.y, v.x, v.y) <= thr;
+            mk[i] = inl ? 1 : 0;
+        }
+        cnt += __popcll(__ballot(inl));
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) s.E[k] = E[k];
+        s.n_inliers = total;
+        s.status = VO_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// recoverPose
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pose_setup(const double* __restrict__ E, size_t e_stride, PoseState* __restrict__ ps,
+                             int npairs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const double* e = E + p * e_stride;
+    PoseState& s = ps[p];
+    double Ev[9], R1[9], R2[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Ev[k] = e[k];
+    decompose_essential(Ev, R1, R2, t);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        s.R1[k] = R1[k];
+        s.R2[k] = R2[k];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const double* R = (c & 1) ? R2 : R1;
+        const double sg = c < 2 ? 1.0 : -1.0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) s.P[c][4 * r + k] = R[3 * r + k];
+            s.P[c][4 * r + 3] = sg * t[r];
+        }
+        s.good[c] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) s.t[r] = t[r];
+}
+
+__global__ __launch_bounds__(256) void k_pose_points(PoseState* __restrict__ ps, const double2* __restrict__ x1,
+                                                     const double2* __restrict__ x2, const int* __restrict__ d_n,
+                                                     int n_host, int n_cap, const uint8_t* __restrict__ mask_in,
+                                                     double dist, double* __restrict__ q4,
+                                                     uint8_t* __restrict__ cmask) {
+    const int pair = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(d_n ? d_n[pair] : n_host, n_cap);
+    const bool ok = i < n;
+    PoseState& s = ps[pair];
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double2 u = make_double2(0, 0), v = u;
+    if (ok) {
+        u = x1[(size_t)pair * n_cap + i];
+        v = x2[(size_t)pair * n_cap + i];
+    }
+    const uint8_t min_ = (ok && mask_in) ? mask_in[(size_t)pair * n_cap + i] : 0xff;
+    for (int c = 0; c < 4; c++) {
+        bool m = false;
+        if (ok) {
+            double P1[12], X[4];
+#pragma unroll
+            for (int k = 0; k < 12; k++) P1[k] = s.P[c][k];
+            triangulate_point(P0, P1, u.x, u.y, v.x, v.y, X);
+            double* q = q4 + (((size_t)pair * 4 + c) * 4) * n_cap + i;
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[(size_t)k * n_cap] = X[k];
+            m = X[2] * X[3] > 0;
+            const double xn = X[0] / X[3], yn = X[1] / X[3], zn = X[2] / X[3], wn = X[3] / X[3];
+            m = (zn < dist) && m;
+            double z2 = 0;
+            z2 += P1[8] * xn;
+            z2 += P1[9] * yn;
+            z2 += P1[10] * zn;
+            z2 += P1[11] * wn;
+            m = (z2 > 0) && m;
+            m = (z2 < dist) && m;
+            const uint8_t mv = (uint8_t)((m ? 255 : 0) & min_);
+            cmask[((size_t)pair * 4 + c) * n_cap + i] = mv;
+            m = mv != 0;
+        }
+        const int cnt = __popcll(__ballot(m));
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s.good[c], cnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pose_select(PoseState* __restrict__ ps, const int* __restrict__ d_n,
+                                                     int n_host, int n_cap, const double* __restrict__ q4,
+                                                     const uint8_t* __restrict__ cmask, uint8_t* __restrict__ mask_out,
+                                                     double* __restrict__ pts4) {
+    const int pair = blockIdx.x;
+    PoseState& s = ps[pair];
+    const int n = min(d_n ? d_n[pair] : n_host, n_cap);
+    const int g0 = s.good[0], g1 = s.good[1], g2 = s.good[2], g3 = s.good[3];
+    int win;
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) win = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) win = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) win = 2;
+    else win = 3;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        mask_out[(size_t)pair * n_cap + i] = cmask[((size_t)pair * 4 + win) * n_cap + i];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            pts4[((size_t)pair * 4 + k) * n_cap + i] = q4[(((size_t)pair * 4 + win) * 4 + k) * n_cap + i];
+    }
+    if (threadIdx.x == 0) {
+        const double* R = (win & 1) ? s.R2 : s.R1;
+        const double sg = win < 2 ? 1.0 : -1.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) s.R[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) s.tt[k] = sg * s.t[k];
+        s.win = win;
+        s.n_good = win == 0 ? g0 : win == 1 ? g1 : win == 2 ? g2 : g3;
+    }
+}
+
+// triangulate(): cv::triangulatePoints on pixel coordinates + points4DToVec
+__global__ __launch_bounds__(256) void k_triangulate(const double* __restrict__ P, const float2* __restrict__ p0,
+                                                     const float2* __restrict__ p1, int n,
+                                                     double* __restrict__ pts3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double P0[12], P1[12], X[4];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        P0[k] = P[k];
+        P1[k] = P[12 + k];
+    }
+    const float2 a = p0[i], b = p1[i];
+    triangulate_point(P0, P1, (double)a.x, (double)a.y, (double)b.x, (double)b.y, X);
+    pts3[3 * (size_t)i + 0] = X[0] / X[3];
+    pts3[3 * (size_t)i + 1] = X[1] / X[3];
+    pts3[3 * (size_t)i + 2] = X[2] / X[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_est_init(hipStream_t st, EstState* s, const int* d_n, int n_host, int n_cap, int niters, float thr_f,
+                     int npairs) {
+    hipLaunchKernelGGL(k_est_init, dim3(cdiv(npairs, 64)), dim3(64), 0, st, s, d_n, n_host, n_cap, niters, thr_f,
+                       npairs);
+}
+
+void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const CamK* cam, const EstState* s,
+                      const int* d_n, int n_host, int n_cap, int n_grid, double2* x1, double2* x2, int npairs) {
+    if (n_grid <= 0) return;
+    hipLaunchKernelGGL(k_normalize, dim3(cdiv(n_grid, 256), npairs), dim3(256), 0, st, p0, p1, cam, s, d_n, n_host,
+                       n_cap, x1, x2);
+}
+
+void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
+                   const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H,
+                   int npairs) {
+    hipLaunchKernelGGL(k_solve5, dim3(cdiv(h1 - h0, 64), npairs), dim3(64), 0, st, h0, h1, s, samples, samples_iters,
+                       x1, x2, n_cap, models, nmodels, H);
+}
+
+void launch_score(hipStream_t st, int h0, int h1, const EstState* s, const double2* x1, const double2* x2, int n_cap,
+                  const double* models, const int* nmodels, int* counts, int H, int npairs) {
+    hipLaunchKernelGGL(k_score, dim3(cdiv(h1 - h0, 4), npairs), dim3(256), 0, st, h0, h1, s, x1, x2, n_cap, models,
+                       nmodels, counts, H);
+}
+
+void launch_replay(hipStream_t st, int h0, int h1, EstState* s, const int* nmodels, const int* counts, int H,
+                   double prob, int npairs) {
+    hipLaunchKernelGGL(k_replay, dim3(npairs), dim3(64), 0, st, h0, h1, s, nmodels, counts, H, prob);
+}
+
+void launch_lmeds(hipStream_t st, EstState* s, const double2* x1, const double2* x2, int n_cap, const double* models,
+                  const int* nmodels, double* medians, int H, int niters, int npairs) {
+    const size_t lds = (size_t)4 * n_cap * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_lmeds_medians, dim3(cdiv(niters * 10, 4), npairs), dim3(256), lds, st, s, x1, x2, n_cap,
+                       models, nmodels, medians, H);
+    hipLaunchKernelGGL(k_lmeds_select, dim3(npairs), dim3(64), 0, st, s, nmodels, medians, H);
+}
+
+void launch_est_finish(hipStream_t st, EstState* s, const double2* x1, const double2* x2, int n_cap,
+                       const double* models, uint8_t* mask, int H, int npairs) {
+    hipLaunchKernelGGL(k_est_finish, dim3(npairs), dim3(256), 0, st, s, x1, x2, n_cap, models, mask, H);
+}
+
+void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps, const double2* x1,
+                 const double2* x2, const int* d_n, int n_host, int n_cap, int n_grid, const uint8_t* mask_in,
+                 double dist, double* q4, uint8_t* cmask, uint8_t* mask_out, double* pts4, int npairs) {
+    hipLaunchKernelGGL(k_pose_setup, dim3(cdiv(npairs, 64)), dim3(64), 0, st, E, e_stride, ps, npairs);
+    if (n_grid > 0)
+        hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
+                           n_cap, mask_in, dist, q4, cmask);
+    hipLaunchKernelGGL(k_pose_select, dim3(npairs), dim3(256), 0, st, ps, d_n, n_host, n_cap, q4, cmask, mask_out,
+                       pts4);
+}
+
+void launch_triangulate(hipStream_t st, const double* P, const float2* p0, const float2* p1, int n, double* pts3) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_triangulate, dim3(cdiv(n, 256)), dim3(256), 0, st, P, p0, p1, n, pts3);
+}

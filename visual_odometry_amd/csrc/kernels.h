@@ -1,0 +1,114 @@
+// kernels.h — device-side data layouts and the launch wrappers of libvo_hip.so's kernels.
+// Internal; the ABI is include/vo_hip.h.
+#ifndef VO_KERNELS_H
+#define VO_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/vo_types.h"
+
+static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- ORB pyramid geometry (one copy on the host, one in device memory) ------------------------
+// Levels live tightly packed per frame: level l at byte `offset`, rows `pitch` bytes apart
+// (pitch = width rounded up to 64).  The same layout is used for the pyramid (levels >= 1; level 0
+// is read from the caller's image), the FAST score map and the blurred pyramid.
+struct LevelGeom {
+    int w, h;
+    int pitch;
+    int row0;         // first row of this level in the frame-wide row table
+    unsigned offset;  // byte offset inside a frame's packed buffer
+    float scale;      // cv layerScale
+};
+struct PyrGeom {
+    int nlevels;
+    int rows_total;      // sum of level heights
+    unsigned pyr_bytes;  // packed bytes per frame
+    int tiles_total;     // 64x16 tiles over all levels
+    int tile_start[VO_ORB_MAX_LEVELS + 1];
+    LevelGeom lv[VO_ORB_MAX_LEVELS];
+};
+
+// where the unblurred pixels of a frame live
+struct FrameSrc {
+    const uint8_t* img;   // level 0: caller's frames
+    size_t frame_stride;  // bytes between frames in img
+    int stride;           // bytes per row in img
+    const uint8_t* pyr;   // packed pyramid (levels >= 1)
+};
+
+struct Taps7 {
+    int t[7];
+};
+
+// candidate corner / selected keypoint in level coordinates (16 bytes)
+struct Cand {
+    int16_t x, y;
+    int16_t level;
+    int16_t score;  // FAST score
+    float harris;   // Harris response (ORB only)
+    uint32_t pad;
+};
+
+// ---- features -----------------------------------------------------------------------------
+void launch_pyr_resize(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
+                       uint8_t* pyr, int level, const uint32_t* xtab, const uint32_t* ytab, int nframes);
+void launch_fast_score(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
+                       uint8_t* score, int threshold, int nframes);
+void launch_nms_count(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
+                      const uint8_t* score, int border, int nms, int* rowcnt, int nframes);
+void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const int* rowcnt, int* rowofs, int* lvlofs,
+                     int nframes);
+void launch_nms_write(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
+                      const uint8_t* score, int border, int nms, int harris, const int* rowofs,
+                      Cand* cand, int max_cand, int nframes);
+void launch_ic_angle(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const Cand* sel,
+                     const int* nkp, int kp_cap, int max_n, vo_keypoint* out, int nframes);
+void launch_gauss7(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
+                   uint8_t* blur, const Taps7& taps, int nlevels_used, int nframes);
+void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,
+                   const int* nkp, int kp_cap, int max_n, uint8_t* desc, int nframes);
+
+// ---- matcher ------------------------------------------------------------------------------
+// Packed neighbour key: distance << 23 | train index (numeric order == (distance, index) order).
+#define VO_KEY_INVALID 0xffffffffu
+#define VO_KEY_SHIFT 23
+struct KnnArgs {
+    const uint32_t* q;    // descriptors, `words` uint32 per row
+    const uint32_t* t;
+    size_t q_stride;      // uint32 between consecutive pairs' query sets
+    size_t t_stride;
+    const int* d_n;       // optional device counts: nq = d_n[pair], nt = d_n[pair + 1]
+    int nq, nt;           // used when d_n == nullptr; otherwise upper bounds for the grid
+    int words;            // 8 (32-byte descriptors) or 16 (64-byte)
+    int splits;           // train range split across blockIdx.y
+    uint2* part;          // [pair][split][nq_cap] partial top-2 keys
+    uint2* knn;           // [pair][nq_cap] merged keys
+    int nq_cap;
+    int npairs;
+};
+void launch_knn2(hipStream_t st, const KnnArgs& a);
+
+struct GoodMatch {
+    int q, t, dist, pad;
+};
+struct FilterArgs {
+    const uint2* knn;          // [pair][nq_cap]
+    const vo_keypoint* kq;     // query keypoints of pair p at kq + p*kp_stride
+    const vo_keypoint* kt;
+    size_t kp_stride;          // in keypoints
+    const int* d_n;            // optional device counts (nq = d_n[pair])
+    int nq;
+    int nq_cap;
+    float ratio, max_disp;
+    GoodMatch* good;           // [pair][nq_cap]
+    float2* p0;                // [pair][nq_cap] compacted query points
+    float2* p1;
+    int* ngood;                // [pair]
+    int npairs;
+};
+void launch_match_filter(hipStream_t st, const FilterArgs& a);
+
+#endif

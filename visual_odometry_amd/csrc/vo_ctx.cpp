@@ -1,0 +1,161 @@
+// vo_ctx.cpp — context lifetime, workspace growth, profiling hooks of libvo_hip.so.
+#include "ctx.h"
+
+int vo_ensure(vo_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return VO_OK;
+    if (b.p) {
+        // the stream may still be using the old allocation
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VO_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    VO_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return VO_OK;
+}
+
+int vo_ensure_pinned(vo_ctx* ctx, PinnedBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return VO_OK;
+    if (b.p) {
+        VO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VO_HIP(ctx, hipHostFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = (bytes + 4095) & ~(size_t)4095;
+    VO_HIP(ctx, hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    b.cap = want;
+    return VO_OK;
+}
+
+int vo_check_launch(vo_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ctx->fail(VO_ERR_DEVICE, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return VO_OK;
+}
+
+extern "C" {
+
+void vo_limits_default(vo_limits* l) {
+    l->max_width = 1241;
+    l->max_height = 376;
+    l->max_features = 8192;
+    l->max_points = 8448;
+    l->max_batch = 64;
+}
+
+void vo_orb_params_default(vo_orb_params* p, int nfeatures) {
+    p->nfeatures = nfeatures;
+    p->scale_factor = 1.2f;
+    p->nlevels = 8;
+    p->edge_threshold = 31;
+    p->first_level = 0;
+    p->wta_k = 2;
+    p->score_type = 0;
+    p->patch_size = 31;
+    p->fast_threshold = 20;
+}
+
+void vo_pair_params_default(vo_pair_params* p, int nfeatures) {
+    vo_orb_params_default(&p->orb, nfeatures);
+    p->ratio = 0.7f;
+    p->max_disp = 200.f;
+    p->prob = 0.999;
+    p->threshold = 1.0;
+    p->dist_thresh = 200.0;
+    p->seed = ~(uint64_t)0;
+    p->max_iters = 1000;
+    p->reserved = 0;
+}
+
+int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VO_ERR_DEVICE;  // no CPU fallback
+    if (device < 0 || device >= ndev) return VO_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return VO_ERR_DEVICE;
+    vo_ctx* c = new vo_ctx();
+    c->device = device;
+    c->err[0] = 0;
+    if (limits) c->lim = *limits;
+    else vo_limits_default(&c->lim);
+    if (c->lim.max_points > 65535 || c->lim.max_features > 262143 || c->lim.max_points < 5 ||
+        c->lim.max_batch < 2 || c->lim.max_width < 7 || c->lim.max_height < 7) {
+        delete c;
+        return VO_ERR_INVALID;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return VO_ERR_DEVICE;
+    }
+    *out = c;
+    return VO_OK;
+}
+
+void vo_ctx_destroy(vo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_rowcnt, &c->d_rowofs,
+                     &c->d_lvlofs, &c->d_cand,  &c->d_sel,   &c->d_coef,   &c->d_geom,   &c->d_kp,
+                     &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,
+                     &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,
+                     &c->d_samples, &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
+                     &c->d_state, &c->d_mask,   &c->d_q4,    &c->d_cmask,  &c->d_pose,   &c->d_pmask,
+                     &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj};
+    for (DevBuf* b : dev)
+        if (b->p) (void)hipFree(b->p);
+    PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_knn,
+                        &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts};
+    for (PinnedBuf* b : pin)
+        if (b->p) (void)hipHostFree(b->p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vo_last_error(const vo_ctx* c) { return c ? c->err : "null context"; }
+
+int vo_ctx_synchronize(vo_ctx* c) {
+    if (!c) return VO_ERR_INVALID;
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_prof_enable(vo_ctx* c, int on) {
+    if (!c) return VO_ERR_INVALID;
+    c->prof_on = on != 0;
+    return VO_OK;
+}
+
+int vo_prof_get(vo_ctx* c, int which, int reset, int* launches, double* total_ms) {
+    if (!c || which < 0 || which >= VO_PROF_COUNT) return VO_ERR_INVALID;
+    if (launches) *launches = c->prof[which].launches;
+    if (total_ms) *total_ms = c->prof[which].total_ms;
+    if (reset) c->prof[which] = ProfSlot();
+    return VO_OK;
+}
+
+void vo_projection_matrix(const double* K, const double* pose, double* P) {
+    // K [R^T | -R^T t], pose = [R | t] camera-to-world (reference: src/sfm/triangulation.cpp:34-44)
+    double M[12];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) M[4 * i + j] = pose[4 * j + i];
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += pose[4 * k + i] * pose[4 * k + 3];
+        M[4 * i + 3] = -s;
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += K[3 * i + k] * M[4 * k + j];
+            P[4 * i + j] = s;
+        }
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// vo_features.cpp — host side of the FAST / ORB entry points: pyramid geometry (cv's level
+// sizes, quotas and INTER_LINEAR_EXACT coefficient tables), kernel sequencing, and the
+// response-ordered keypoint selection (KeyPointsFilter::retainBest) whose output permutation is
+// defined by libstdc++'s nth_element/partition and therefore runs on the host.
+// Replaces FeatureDetector's cv calls (reference: src/features/feature_detector.cpp:3-42).
+#include <algorithm>
+#include <cmath>
+
+#include "ctx.h"
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_roundf(float v) { return (int)std::lrintf(v); }
+inline int cv_floor(double v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+
+bool orb_params_ok(const vo_orb_params* p) {
+    return p && p->nfeatures >= 0 && p->nlevels >= 1 && p->nlevels <= VO_ORB_MAX_LEVELS &&
+           p->first_level == 0 && p->wta_k == 2 && p->score_type == 0 && p->patch_size == 31 &&
+           p->scale_factor > 1.0f && p->edge_threshold >= 0 && p->fast_threshold >= 0;
+}
+
+// interpolationLinear<uchar>::getCoeffs of cv's bit-exact resize: entry = ofs << 16 | c1
+void linear_table(int ssize, int dsize, uint32_t* out) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1.0 / inv_scale;
+    for (int v = 0; v < dsize; v++) {
+        const double fval = scale * ((double)v + 0.5) - 0.5;
+        const int ival = cv_floor(fval);
+        uint32_t ofs, c1;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) {
+                ofs = (uint32_t)ival;
+                c1 = (uint32_t)cv_round((fval - (double)ival) * 256.0);
+            } else {
+                ofs = (uint32_t)(ssize - 1);
+                c1 = 0;
+            }
+        } else {
+            ofs = 0;
+            c1 = 0;
+        }
+        out[v] = (ofs << 16) | c1;
+    }
+}
+
+Taps7 gauss_taps() {
+    // cv::getGaussianKernel(7, 2, CV_32F) scaled to 8 fractional bits
+    Taps7 t;
+    const double sigma = 2.0, scale2X = -0.5 / (sigma * sigma);
+    float cf[7];
+    double sum = 0;
+    for (int i = 0; i < 7; i++) {
+        const double x = i - 3.0;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float)(cf[i] * sum);
+        t.t[i] = cv_round((double)cf[i] * 256.0);
+    }
+    return t;
+}
+
+struct RespIdx {
+    float response;
+    int idx;
+};
+
+// KeyPointsFilter::retainBest (cv 3.4.2)
+void retain_best(std::vector<RespIdx>& v, int n_points) {
+    if (n_points >= 0 && v.size() > (size_t)n_points) {
+        if (n_points == 0) {
+            v.clear();
+            return;
+        }
+        std::nth_element(v.begin(), v.begin() + n_points, v.end(),
+                         [](const RespIdx& a, const RespIdx& b) { return a.response > b.response; });
+        const float ambiguous = v[n_points - 1].response;
+        auto new_end = std::partition(v.begin() + n_points, v.end(),
+                                      [ambiguous](const RespIdx& k) { return k.response >= ambiguous; });
+        v.resize(new_end - v.begin());
+    }
+}
+
+}  // namespace
+
+// Pyramid geometry for (w, h, params); p == nullptr -> single level (plain FAST).
+int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
+    const int nlevels = p ? p->nlevels : 1;
+    const float sf = p ? p->scale_factor : 1.2f;
+    const int nfeatures = p ? p->nfeatures : 0;
+    if (w < 7 || h < 7) return c->fail(VO_ERR_INVALID, "image %dx%d is smaller than the FAST ring", w, h);
+    if (w > c->lim.max_width || h > c->lim.max_height)
+        return c->fail(VO_ERR_CAPACITY, "image %dx%d exceeds the context limits %dx%d", w, h,
+                       c->lim.max_width, c->lim.max_height);
+    if (nframes > c->lim.max_batch)
+        return c->fail(VO_ERR_CAPACITY, "%d frames exceed max_batch %d", nframes, c->lim.max_batch);
+    const bool same = c->geom_w == w && c->geom_h == h && c->geom_levels == nlevels && c->geom_scale == sf;
+    if (!same) {
+        PyrGeom g;
+        memset(&g, 0, sizeof(g));
+        g.nlevels = nlevels;
+        const double scaleFactor = (double)sf;
+        unsigned off = 0;
+        int row = 0, tile = 0;
+        for (int l = 0; l < nlevels; l++) {
+            const float s = (float)std::pow(scaleFactor, (double)l);
+            LevelGeom& L = g.lv[l];
+            L.scale = s;
+            L.w = cv_roundf(w / s);
+            L.h = cv_roundf(h / s);
+            if (L.w < 7 || L.h < 7) return c->fail(VO_ERR_INVALID, "pyramid level %d is too small", l);
+            L.pitch = (L.w + 63) & ~63;
+            L.offset = off;
+            L.row0 = row;
+            off += (unsigned)L.pitch * L.h;
+            off = (off + 255u) & ~255u;
+            row += L.h;
+            g.tile_start[l] = tile;
+            tile += cdiv(L.w, 64) * cdiv(L.h, 16);
+        }
+        g.tile_start[nlevels] = tile;
+        g.tiles_total = tile;
+        g.rows_total = row;
+        g.pyr_bytes = off;
+        // coefficient tables for levels >= 1
+        c->coef_host.clear();
+        c->coef_x.assign(nlevels, 0);
+        c->coef_y.assign(nlevels, 0);
+        for (int l = 1; l < nlevels; l++) {
+            c->coef_x[l] = c->coef_host.size();
+            c->coef_host.resize(c->coef_host.size() + g.lv[l].w);
+            linear_table(g.lv[l - 1].w, g.lv[l].w, &c->coef_host[c->coef_x[l]]);
+            c->coef_y[l] = c->coef_host.size();
+            c->coef_host.resize(c->coef_host.size() + g.lv[l].h);
+            linear_table(g.lv[l - 1].h, g.lv[l].h, &c->coef_host[c->coef_y[l]]);
+        }
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        VO_TRY(vo_ensure(c, c->d_geom, sizeof(PyrGeom)));
+        VO_HIP(c, hipMemcpy(c->d_geom.p, &g, sizeof(PyrGeom), hipMemcpyHostToDevice));
+        if (!c->coef_host.empty()) {
+            VO_TRY(vo_ensure(c, c->d_coef, c->coef_host.size() * sizeof(uint32_t)));
+            VO_HIP(c, hipMemcpy(c->d_coef.p, c->coef_host.data(), c->coef_host.size() * sizeof(uint32_t),
+                                hipMemcpyHostToDevice));
+        }
+        c->geom = g;
+        c->geom_w = w;
+        c->geom_h = h;
+        c->geom_levels = nlevels;
+        c->geom_scale = sf;
+        c->geom_nfeatures = -1;
+    }
+    if (c->geom_nfeatures != nfeatures) {
+        // per-level feature quotas (cv ORB_Impl::detectAndCompute)
+        const float factor = (float)(1.0 / (double)sf);
+        float ndesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; l++) {
+            c->quota[l] = cv_roundf(ndesired);
+            sum += c->quota[l];
+            ndesired *= factor;
+        }
+        c->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+        c->geom_nfeatures = nfeatures;
+    }
+    // workspace
+    const size_t nf = (size_t)nframes;
+    const int kp_cap = std::max(c->lim.max_features, 16) * 2;  // nfeatures + response ties
+    c->kp_cap = kp_cap;
+    VO_TRY(vo_ensure(c, c->d_pyr, nf * c->geom.pyr_bytes));
+    VO_TRY(vo_ensure(c, c->d_blur, nf * c->geom.pyr_bytes));
+    VO_TRY(vo_ensure(c, c->d_score, nf * c->geom.pyr_bytes));
+    VO_TRY(vo_ensure(c, c->d_rowcnt, nf * c->geom.rows_total * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_rowofs, nf * (c->geom.rows_total + 1) * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
+    VO_TRY(vo_ensure(c, c->d_sel, nf * kp_cap * sizeof(Cand)));
+    VO_TRY(vo_ensure(c, c->d_kp, nf * kp_cap * sizeof(vo_keypoint)));
+    VO_TRY(vo_ensure(c, c->d_desc, nf * kp_cap * 32));
+    VO_TRY(vo_ensure(c, c->d_nkp, (nf + 1) * sizeof(int)));
+    VO_TRY(vo_ensure_pinned(c, c->h_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
+    VO_TRY(vo_ensure_pinned(c, c->h_cand, nf * c->max_cand * sizeof(Cand)));
+    VO_TRY(vo_ensure_pinned(c, c->h_sel, nf * kp_cap * sizeof(Cand)));
+    VO_TRY(vo_ensure_pinned(c, c->h_nkp, (nf + 1) * sizeof(int)));
+    c->feat_frames = nframes;
+    return VO_OK;
+}
+
+// Stage A: pyramid, FAST score, NMS + border filter + ordered compaction (+ Harris).  On return
+// h_lvlofs[f][0..nlevels] and h_cand[f][0..total) are valid on the host.
+int feat_detect(vo_ctx* c, const FrameSrc& src_in, int nframes, int fast_threshold, int border, int nms,
+                int harris) {
+    const PyrGeom& g = c->geom;
+    const PyrGeom* dg = c->d_geom.as<PyrGeom>();
+    FrameSrc src = src_in;
+    src.pyr = c->d_pyr.as<uint8_t>();
+    hipStream_t st = c->stream;
+    for (int l = 1; l < g.nlevels; l++)
+        launch_pyr_resize(st, src, dg, g, c->d_pyr.as<uint8_t>(), l, c->d_coef.as<uint32_t>() + c->coef_x[l],
+                          c->d_coef.as<uint32_t>() + c->coef_y[l], nframes);
+    {
+        ProfScope ps(c, VO_PROF_FAST);
+        launch_fast_score(st, src, dg, g, c->d_score.as<uint8_t>(), std::min(std::max(fast_threshold, 0), 255),
+                          nframes);
+    }
+    launch_nms_count(st, src, dg, g, c->d_score.as<uint8_t>(), border, nms, c->d_rowcnt.as<int>(), nframes);
+    launch_row_scan(st, dg, c->d_rowcnt.as<int>(), c->d_rowofs.as<int>(), c->d_lvlofs.as<int>(), nframes);
+    launch_nms_write(st, src, dg, g, c->d_score.as<uint8_t>(), border, nms, harris, c->d_rowofs.as<int>(),
+                     c->d_cand.as<Cand>(), c->max_cand, nframes);
+    VO_TRY(vo_check_launch(c, "feature detection"));
+    const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
+    VO_HIP(c, hipMemcpyAsync(c->h_lvlofs.p, c->d_lvlofs.p, lv_bytes, hipMemcpyDeviceToHost, st));
+    VO_HIP(c, hipStreamSynchronize(st));
+    const int* lv = c->h_lvlofs.as<int>();
+    for (int f = 0; f < nframes; f++) {
+        const int total = lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels];
+        if (total > c->max_cand)
+            return c->fail(VO_ERR_CAPACITY, "frame %d has %d FAST candidates, workspace holds %d", f, total,
+                           c->max_cand);
+        if (total > 0)
+            VO_HIP(c, hipMemcpyAsync(c->h_cand.as<Cand>() + (size_t)f * c->max_cand,
+                                     c->d_cand.as<Cand>() + (size_t)f * c->max_cand, (size_t)total * sizeof(Cand),
+                                     hipMemcpyDeviceToHost, st));
+    }
+    VO_HIP(c, hipStreamSynchronize(st));
+    return VO_OK;
+}
+
+// ORB keypoint selection per frame and level: retainBest(2*quota) on the FAST score, then
+// retainBest(quota) on the Harris response, in cv's order.  Uploads the selection.
+int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out) {
+    const PyrGeom& g = c->geom;
+    const int* lv = c->h_lvlofs.as<int>();
+    int* nkp = c->h_nkp.as<int>();
+    std::vector<RespIdx> v;
+    int max_n = 0;
+    for (int f = 0; f < nframes; f++) {
+        const Cand* cand = c->h_cand.as<Cand>() + (size_t)f * c->max_cand;
+        Cand* sel = c->h_sel.as<Cand>() + (size_t)f * c->kp_cap;
+        int n = 0;
+        for (int l = 0; l < g.nlevels; l++) {
+            const int b = lv[f * (VO_ORB_MAX_LEVELS + 1) + l], e = lv[f * (VO_ORB_MAX_LEVELS + 1) + l + 1];
+            v.resize(e - b);
+            for (int i = b; i < e; i++) v[i - b] = {(float)cand[i].score, i};
+            retain_best(v, 2 * c->quota[l]);
+            for (auto& r : v) r.response = cand[r.idx].harris;
+            retain_best(v, c->quota[l]);
+            if (n + (int)v.size() > c->kp_cap)
+                return c->fail(VO_ERR_CAPACITY, "frame %d selects more than %d keypoints", f, c->kp_cap);
+            for (auto& r : v) sel[n++] = cand[r.idx];
+        }
+        nkp[f] = n;
+        max_n = std::max(max_n, n);
+        if (n > 0)
+            VO_HIP(c, hipMemcpyAsync(c->d_sel.as<Cand>() + (size_t)f * c->kp_cap, sel, (size_t)n * sizeof(Cand),
+                                     hipMemcpyHostToDevice, c->stream));
+    }
+    nkp[nframes] = 0;
+    VO_HIP(c, hipMemcpyAsync(c->d_nkp.p, nkp, (size_t)(nframes + 1) * sizeof(int), hipMemcpyHostToDevice,
+                             c->stream));
+    *max_n_out = max_n;
+    return VO_OK;
+}
+
+// Stage B: IC angles (optional), blur, rBRIEF for nkp[f] keypoints per frame.
+int feat_describe(vo_ctx* c, const FrameSrc& src_in, int nframes, int max_n, bool angles) {
+    static const Taps7 taps = gauss_taps();
+    const PyrGeom& g = c->geom;
+    const PyrGeom* dg = c->d_geom.as<PyrGeom>();
+    FrameSrc src = src_in;
+    src.pyr = c->d_pyr.as<uint8_t>();
+    if (angles)
+        launch_ic_angle(c->stream, src, dg, c->d_sel.as<Cand>(), c->d_nkp.as<int>(), c->kp_cap, max_n,
+                        c->d_kp.as<vo_keypoint>(), nframes);
+    launch_gauss7(c->stream, src, dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
+    launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
+                  c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
+    return vo_check_launch(c, "feature description");
+}
+
+static int upload_image(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, FrameSrc& src) {
+    const int pitch = (w + 63) & ~63;
+    VO_TRY(vo_ensure(c, c->d_img, (size_t)pitch * h));
+    VO_HIP(c, hipMemcpy2DAsync(c->d_img.p, pitch, gray, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    src.img = c->d_img.as<uint8_t>();
+    src.frame_stride = (size_t)pitch * h;
+    src.stride = pitch;
+    src.pyr = nullptr;
+    return VO_OK;
+}
+
+extern "C" {
+
+int vo_fast_detect(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, int threshold, int nms,
+                   vo_keypoint* out, int cap, int* n) {
+    if (!c) return VO_ERR_INVALID;
+    if (!gray || !n || w <= 0 || h <= 0 || stride < w || cap < 0 || (cap > 0 && !out))
+        return c->fail(VO_ERR_INVALID, "vo_fast_detect: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    *n = 0;
+    if (w < 7 || h < 7) return VO_OK;  // cv: no pixel has a full ring
+    VO_TRY(feat_setup(c, w, h, nullptr, 1));
+    FrameSrc src;
+    VO_TRY(upload_image(c, gray, w, h, stride, src));
+    VO_TRY(feat_detect(c, src, 1, threshold, 0, nms != 0, 0));
+    const int total = c->h_lvlofs.as<int>()[1];
+    const Cand* cand = c->h_cand.as<Cand>();
+    *n = total;
+    for (int i = 0; i < total && i < cap; i++) {
+        vo_keypoint k;
+        k.x = (float)cand[i].x;
+        k.y = (float)cand[i].y;
+        k.size = 7.f;
+        k.angle = -1.f;
+        k.response = (float)cand[i].score;
+        k.octave = 0;
+        k.class_id = -1;
+        out[i] = k;
+    }
+    if (total > cap) return c->fail(VO_ERR_CAPACITY, "vo_fast_detect: %d keypoints, capacity %d", total, cap);
+    return VO_OK;
+}
+
+int vo_orb_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, const vo_orb_params* p,
+                          vo_keypoint* kp, uint8_t* desc, int cap, int* n) {
+    if (!c) return VO_ERR_INVALID;
+    if (!gray || !n || w <= 0 || h <= 0 || stride < w || cap < 0 || !orb_params_ok(p))
+        return c->fail(VO_ERR_INVALID, "vo_orb_detect_compute: bad argument or unsupported ORB parameter");
+    if (p->nfeatures > c->lim.max_features)
+        return c->fail(VO_ERR_CAPACITY, "nfeatures %d exceeds max_features %d", p->nfeatures,
+                       c->lim.max_features);
+    VO_HIP(c, hipSetDevice(c->device));
+    *n = 0;
+    VO_TRY(feat_setup(c, w, h, p, 1));
+    FrameSrc src;
+    VO_TRY(upload_image(c, gray, w, h, stride, src));
+    VO_TRY(feat_detect(c, src, 1, p->fast_threshold, p->edge_threshold, 1, 1));
+    int max_n = 0;
+    VO_TRY(feat_select_orb(c, 1, &max_n));
+    const int cnt = c->h_nkp.as<int>()[0];
+    *n = cnt;
+    if (cnt > cap) return c->fail(VO_ERR_CAPACITY, "vo_orb_detect_compute: %d keypoints, capacity %d", cnt, cap);
+    if (cnt == 0) return VO_OK;
+    VO_TRY(feat_describe(c, src, 1, max_n, true));
+    if (kp) VO_HIP(c, hipMemcpyAsync(kp, c->d_kp.p, (size_t)cnt * sizeof(vo_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (desc) VO_HIP(c, hipMemcpyAsync(desc, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+int vo_orb_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, const vo_orb_params* p,
+                   vo_keypoint* kp, int* n_inout, uint8_t* desc) {
+    if (!c) return VO_ERR_INVALID;
+    if (!gray || !n_inout || *n_inout < 0 || w <= 0 || h <= 0 || stride < w || !orb_params_ok(p) ||
+        (*n_inout > 0 && (!kp || !desc)))
+        return c->fail(VO_ERR_INVALID, "vo_orb_compute: bad argument or unsupported ORB parameter");
+    VO_HIP(c, hipSetDevice(c->device));
+    const int n_in = *n_inout;
+    // KeyPointsFilter::runByImageBorder on level-0 coordinates, then stable grouping by octave
+    std::vector<vo_keypoint> kept;
+    const int b = p->edge_threshold;
+    int nlevels = 0;
+    for (int i = 0; i < n_in; i++) {
+        const vo_keypoint& k = kp[i];
+        if (w > 2 * b && h > 2 * b && k.x >= (float)b && k.x < (float)(w - b) && k.y >= (float)b &&
+            k.y < (float)(h - b)) {
+            if (k.octave < 0 || k.octave >= VO_ORB_MAX_LEVELS)
+                return c->fail(VO_ERR_INVALID, "vo_orb_compute: keypoint octave %d out of range", k.octave);
+            nlevels = std::max(nlevels, k.octave);
+            kept.push_back(k);
+        }
+    }
+    nlevels++;
+    std::vector<vo_keypoint> sorted;
+    sorted.reserve(kept.size());
+    for (int l = 0; l < nlevels; l++)
+        for (const auto& k : kept)
+            if (k.octave == l) sorted.push_back(k);
+    const int cnt = (int)sorted.size();
+    *n_inout = cnt;
+    if (cnt == 0) return VO_OK;
+    if (cnt > 2 * c->lim.max_features)
+        return c->fail(VO_ERR_CAPACITY, "vo_orb_compute: %d keypoints exceed the workspace (%d)", cnt,
+                       2 * c->lim.max_features);
+    vo_orb_params pp = *p;
+    pp.nlevels = nlevels;  // only the levels the keypoints use are built
+    VO_TRY(feat_setup(c, w, h, &pp, 1));
+    FrameSrc src;
+    VO_TRY(upload_image(c, gray, w, h, stride, src));
+    src.pyr = c->d_pyr.as<uint8_t>();
+    for (int l = 1; l < c->geom.nlevels; l++)
+        launch_pyr_resize(c->stream, src, c->d_geom.as<PyrGeom>(), c->geom, c->d_pyr.as<uint8_t>(), l,
+                          c->d_coef.as<uint32_t>() + c->coef_x[l], c->d_coef.as<uint32_t>() + c->coef_y[l], 1);
+    int* nkp = c->h_nkp.as<int>();
+    nkp[0] = cnt;
+    nkp[1] = 0;
+    VO_HIP(c, hipMemcpyAsync(c->d_nkp.p, nkp, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->d_kp.p, sorted.data(), (size_t)cnt * sizeof(vo_keypoint), hipMemcpyHostToDevice,
+                             c->stream));
+    VO_TRY(feat_describe(c, src, 1, cnt, false));
+    VO_HIP(c, hipMemcpyAsync(desc, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(kp, sorted.data(), (size_t)cnt * sizeof(vo_keypoint));
+    return VO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// vo_geometry.cpp — host side of findEssentialMat / recoverPose / triangulate.
+// Replaces the cv calls of matcher() and updatePose() (reference: src/matcher/matcher.cpp:42,
+// src/visual_odometry/vo_pose.h:14,19,22, src/sfm/triangulation.cpp:46-66).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <thread>
+
+#include "ctx.h"
+#include "geom_types.h"
+
+namespace {
+
+// cv::RNG (multiply-with-carry) and PointSetRegistrator::getSubset: the 5-subsets depend only on
+// the seed and the point count, so they are tabulated once per context for every n and kept in
+// HBM; the kernels then need no host round trip to learn n.
+struct CvRng {
+    uint64_t state;
+    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffu) {}
+    uint32_t next() {
+        state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
+};
+
+void fill_subsets(uint64_t seed, int n, int iters, uint16_t* out) {
+    CvRng rng(seed);
+    for (int it = 0; it < iters; it++) {
+        int idx[5];
+        for (int i = 0; i < 5; i++) {
+            for (;;) {
+                const int v = idx[i] = rng.uniform(0, n);
+                int j;
+                for (j = 0; j < i; j++)
+                    if (v == idx[j]) break;
+                if (j == i) break;
+            }
+        }
+        for (int i = 0; i < 5; i++) out[(size_t)it * 5 + i] = (uint16_t)idx[i];
+    }
+}
+
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = std::max(p, 0.);
+    p = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)std::lrint(num / denom);
+}
+
+}  // namespace
+
+// Sample table + per-pair workspace for npairs problems of up to n_cap points, H hypotheses.
+int geom_prepare(vo_ctx* c, int npairs, int n_cap, uint64_t seed, int H) {
+    if (n_cap > c->lim.max_points)
+        return c->fail(VO_ERR_CAPACITY, "%d points exceed max_points %d", n_cap, c->lim.max_points);
+    if (H < 1 || H > 65536) return c->fail(VO_ERR_INVALID, "max_iters %d out of range", H);
+    if (c->samples_seed != seed || c->samples_iters < H || c->samples_max_n < c->lim.max_points || !c->d_samples.p) {
+        const int iters = std::max(H, 1000);
+        const int maxn = c->lim.max_points;
+        std::vector<uint16_t> tab((size_t)(maxn + 1) * iters * 5, 0);
+        const int nthreads = 8;
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+            th.emplace_back([&, t]() {
+                for (int n = 5 + t; n <= maxn; n += nthreads)
+                    fill_subsets(seed, n, iters, &tab[(size_t)n * iters * 5]);
+            });
+        for (auto& x : th) x.join();
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        VO_TRY(vo_ensure(c, c->d_samples, tab.size() * sizeof(uint16_t)));
+        VO_HIP(c, hipMemcpy(c->d_samples.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        c->samples_seed = seed;
+        c->samples_iters = iters;
+        c->samples_max_n = maxn;
+    }
+    const size_t np = (size_t)npairs;
+    VO_TRY(vo_ensure(c, c->d_x1, np * n_cap * sizeof(double2)));
+    VO_TRY(vo_ensure(c, c->d_x2, np * n_cap * sizeof(double2)));
+    VO_TRY(vo_ensure(c, c->d_models, np * H * 90 * sizeof(double)));
+    VO_TRY(vo_ensure(c, c->d_nmodels, np * H * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_counts, np * H * 10 * sizeof(double)));
+    VO_TRY(vo_ensure(c, c->d_state, np * sizeof(EstState)));
+    VO_TRY(vo_ensure(c, c->d_mask, np * n_cap));
+    VO_TRY(vo_ensure(c, c->d_cam, np * sizeof(CamK)));
+    return VO_OK;
+}
+
+// Essential matrix for npairs point sets resident on the device (points of pair p at
+// d_p0 + p*n_cap).  Leaves EstState[p] (E, status, n_inliers) and d_mask on the device.
+int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0, const float2* d_p1,
+                            const int* d_n, int n_host, const double* K, int method, double prob,
+                            double threshold, int max_iters) {
+    hipStream_t st = c->stream;
+    const double fx = K[0], fy = K[4];
+    const double thr = threshold / ((fx + fy) / 2);
+    const float thr_f = (float)(thr * thr);
+    const int H = std::max(max_iters, 1);
+    int niters = H;
+    if (method == VO_LMEDS) niters = std::min(H, std::max(ransac_update_num_iters(prob, 0.45, 5, H), 3));
+    // camera (same K for every pair)
+    VO_TRY(vo_ensure_pinned(c, c->h_misc, std::max((size_t)npairs * sizeof(CamK), (size_t)4096)));
+    CamK* hk = c->h_misc.as<CamK>();
+    for (int p = 0; p < npairs; p++) hk[p] = {K[0], K[4], K[2], K[5]};
+    VO_HIP(c, hipMemcpyAsync(c->d_cam.p, hk, (size_t)npairs * sizeof(CamK), hipMemcpyHostToDevice, st));
+
+    EstState* S = c->d_state.as<EstState>();
+    double2* x1 = c->d_x1.as<double2>();
+    double2* x2 = c->d_x2.as<double2>();
+    double* models = c->d_models.as<double>();
+    int* nmodels = c->d_nmodels.as<int>();
+    const uint16_t* samples = c->d_samples.as<uint16_t>();
+    const int n_grid = d_n ? n_cap : n_host;
+
+    launch_est_init(st, S, d_n, n_host, n_cap, niters, thr_f, npairs);
+    launch_normalize(st, d_p0, d_p1, c->d_cam.as<CamK>(), S, nullptr, 0, n_cap, n_grid, x1, x2, npairs);
+    if (method == VO_RANSAC) {
+        // hypotheses are evaluated in growing chunks; a chunk whose first index is already past
+        // the (shrinking) iteration cap exits at once, so typical inputs run only the first one
+        // or two, with the same result as evaluating all of them.
+        int h0 = 0, size = 64;
+        while (h0 < H) {
+            const int h1 = std::min(H, h0 + size);
+            {
+                ProfScope ps(c, VO_PROF_SOLVE);
+                launch_solve5(st, h0, h1, S, samples, c->samples_iters, x1, x2, n_cap, models, nmodels, H, npairs);
+            }
+            launch_score(st, h0, h1, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<int>(), H, npairs);
+            launch_replay(st, h0, h1, S, nmodels, c->d_counts.as<int>(), H, prob, npairs);
+            h0 = h1;
+            size *= 2;
+        }
+    } else {
+        {
+            ProfScope ps(c, VO_PROF_SOLVE);
+            launch_solve5(st, 0, niters, S, samples, c->samples_iters, x1, x2, n_cap, models, nmodels, H, npairs);
+        }
+        launch_lmeds(st, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<double>(), H, niters, npairs);
+    }
+    launch_est_finish(st, S, x1, x2, n_cap, models, c->d_mask.as<uint8_t>(), H, npairs);
+    return vo_check_launch(c, "findEssentialMat");
+}
+
+// recoverPose for npairs point sets; E of pair p at d_E + p*e_stride.  Uses d_x1/d_x2 if
+// `normalized` (left by geom_find_essential_dev), else normalises d_p0/d_p1 first.
+int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, size_t e_stride,
+                          const float2* d_p0, const float2* d_p1, const int* d_n, int n_host, const double* K,
+                          double dist_thresh, bool use_mask) {
+    hipStream_t st = c->stream;
+    const size_t np = (size_t)npairs;
+    VO_TRY(vo_ensure(c, c->d_q4, np * 16 * n_cap * sizeof(double)));
+    VO_TRY(vo_ensure(c, c->d_cmask, np * 4 * n_cap));
+    VO_TRY(vo_ensure(c, c->d_pose, np * sizeof(PoseState)));
+    VO_TRY(vo_ensure(c, c->d_pmask, np * n_cap));
+    VO_TRY(vo_ensure(c, c->d_pts4, np * 4 * n_cap * sizeof(double)));
+    const int n_grid = d_n ? n_cap : n_host;
+    if (d_p0) {
+        VO_TRY(vo_ensure_pinned(c, c->h_misc, std::max(np * sizeof(CamK), (size_t)4096)));
+        CamK* hk = c->h_misc.as<CamK>();
+        for (int p = 0; p < npairs; p++) hk[p] = {K[0], K[4], K[2], K[5]};
+        VO_HIP(c, hipMemcpyAsync(c->d_cam.p, hk, np * sizeof(CamK), hipMemcpyHostToDevice, st));
+        launch_normalize(st, d_p0, d_p1, c->d_cam.as<CamK>(), nullptr, d_n, n_host, n_cap, n_grid,
+                         c->d_x1.as<double2>(), c->d_x2.as<double2>(), npairs);
+    }
+    launch_pose(st, d_E, e_stride, c->d_pose.as<PoseState>(), c->d_x1.as<double2>(), c->d_x2.as<double2>(), d_n,
+                n_host, n_cap, n_grid, use_mask ? c->d_mask.as<uint8_t>() : nullptr, dist_thresh,
+                c->d_q4.as<double>(), c->d_cmask.as<uint8_t>(), c->d_pmask.as<uint8_t>(), c->d_pts4.as<double>(),
+                npairs);
+    return vo_check_launch(c, "recoverPose");
+}
+
+static int upload_points(vo_ctx* c, const float* p0, const float* p1, int n) {
+    VO_TRY(vo_ensure(c, c->d_fp0, (size_t)std::max(n, 1) * sizeof(float2)));
+    VO_TRY(vo_ensure(c, c->d_fp1, (size_t)std::max(n, 1) * sizeof(float2)));
+    if (n > 0) {
+        VO_HIP(c, hipMemcpyAsync(c->d_fp0.p, p0, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        VO_HIP(c, hipMemcpyAsync(c->d_fp1.p, p1, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    }
+    return VO_OK;
+}
+
+extern "C" {
+
+int vo_find_essential(vo_ctx* c, const float* p0, const float* p1, int n, const double* K, int method,
+                      double prob, double threshold, uint64_t seed, int max_iters, double* E, uint8_t* mask) {
+    if (!c) return VO_ERR_INVALID;
+    if (n < 0 || !K || !E || (n > 0 && (!p0 || !p1)) || !(prob > 0 && prob < 1) ||
+        (method != VO_RANSAC && method != VO_LMEDS) || max_iters < 1)
+        return c->fail(VO_ERR_INVALID, "vo_find_essential: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < 9; i++) E[i] = 0;
+    if (mask && n > 0) memset(mask, 0, n);
+    if (n < 5) return c->fail(VO_ERR_FAILED, "vo_find_essential: %d points, 5 needed", n);
+    VO_TRY(geom_prepare(c, 1, n, seed, max_iters));
+    VO_TRY(upload_points(c, p0, p1, n));
+    VO_TRY(geom_find_essential_dev(c, 1, n, c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), nullptr, n, K, method,
+                                   prob, threshold, max_iters));
+    VO_TRY(vo_ensure_pinned(c, c->h_state, sizeof(EstState)));
+    VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, sizeof(EstState), hipMemcpyDeviceToHost, c->stream));
+    if (mask) VO_HIP(c, hipMemcpyAsync(mask, c->d_mask.p, n, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    const EstState* s = c->h_state.as<EstState>();
+    if (s->status != VO_OK) {
+        if (mask) memset(mask, 0, n);
+        return c->fail(VO_ERR_FAILED, "vo_find_essential: no model found");
+    }
+    memcpy(E, s->E, 9 * sizeof(double));
+    return VO_OK;
+}
+
+int vo_recover_pose(vo_ctx* c, const double* E, const float* p0, const float* p1, int n, const double* K,
+                    double dist_thresh, uint8_t* mask_inout, double* R, double* t, double* pts4d, int* n_good) {
+    if (!c) return VO_ERR_INVALID;
+    if (n < 0 || !E || !K || !R || !t || (n > 0 && (!p0 || !p1)))
+        return c->fail(VO_ERR_INVALID, "vo_recover_pose: bad argument");
+    if (n > c->lim.max_points)
+        return c->fail(VO_ERR_CAPACITY, "vo_recover_pose: %d points exceed max_points %d", n, c->lim.max_points);
+    VO_HIP(c, hipSetDevice(c->device));
+    const int n_cap = std::max(n, 1);
+    VO_TRY(vo_ensure(c, c->d_x1, (size_t)n_cap * sizeof(double2)));
+    VO_TRY(vo_ensure(c, c->d_x2, (size_t)n_cap * sizeof(double2)));
+    VO_TRY(vo_ensure(c, c->d_mask, (size_t)n_cap));
+    VO_TRY(vo_ensure(c, c->d_cam, sizeof(CamK)));
+    VO_TRY(vo_ensure(c, c->d_proj, 24 * sizeof(double)));
+    VO_TRY(upload_points(c, p0, p1, n));
+    VO_HIP(c, hipMemcpyAsync(c->d_proj.p, E, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (mask_inout && n > 0)
+        VO_HIP(c, hipMemcpyAsync(c->d_mask.p, mask_inout, n, hipMemcpyHostToDevice, c->stream));
+    VO_TRY(geom_recover_pose_dev(c, 1, n_cap, c->d_proj.as<double>(), 0, c->d_fp0.as<float2>(),
+                                 c->d_fp1.as<float2>(), nullptr, n, K, dist_thresh, mask_inout != nullptr));
+    VO_TRY(vo_ensure_pinned(c, c->h_pose, sizeof(PoseState)));
+    VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
+    if (mask_inout && n > 0)
+        VO_HIP(c, hipMemcpyAsync(mask_inout, c->d_pmask.p, n, hipMemcpyDeviceToHost, c->stream));
+    if (pts4d && n > 0)
+        for (int k = 0; k < 4; k++)
+            VO_HIP(c, hipMemcpyAsync(pts4d + (size_t)k * n, c->d_pts4.as<double>() + (size_t)k * n_cap,
+                                     (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    const PoseState* s = c->h_pose.as<PoseState>();
+    memcpy(R, s->R, 9 * sizeof(double));
+    memcpy(t, s->tt, 3 * sizeof(double));
+    if (n_good) *n_good = s->n_good;
+    return VO_OK;
+}
+
+int vo_triangulate(vo_ctx* c, const float* p0, const float* p1, int n, const double* P0, const double* P1,
+                   double* pts3d) {
+    if (!c) return VO_ERR_INVALID;
+    if (n < 0 || !P0 || !P1 || (n > 0 && (!p0 || !p1 || !pts3d)))
+        return c->fail(VO_ERR_INVALID, "vo_triangulate: bad argument");
+    if (n == 0) return VO_OK;  // the reference returns an empty vector (triangulation.cpp:49-51)
+    VO_HIP(c, hipSetDevice(c->device));
+    VO_TRY(upload_points(c, p0, p1, n));
+    VO_TRY(vo_ensure(c, c->d_proj, 24 * sizeof(double)));
+    VO_TRY(vo_ensure(c, c->d_pts4, (size_t)n * 3 * sizeof(double)));
+    double P[24];
+    memcpy(P, P0, 12 * sizeof(double));
+    memcpy(P + 12, P1, 12 * sizeof(double));
+    VO_HIP(c, hipMemcpyAsync(c->d_proj.p, P, sizeof(P), hipMemcpyHostToDevice, c->stream));
+    launch_triangulate(c->stream, c->d_proj.as<double>(), c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), n,
+                       c->d_pts4.as<double>());
+    VO_TRY(vo_check_launch(c, "triangulate"));
+    VO_HIP(c, hipMemcpyAsync(pts3d, c->d_pts4.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
+}  // extern "C"

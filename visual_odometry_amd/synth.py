@@ -139,7 +139,7 @@ def write_kitti_layout(root, seq_id, frames, poses, K=KITTI_K):
     os.makedirs(os.path.join(root, "poses"), exist_ok=True)
     for k, f in enumerate(frames):
         Image.fromarray(f, mode="L").save(os.path.join(img_dir, "%06d.png" % k))
-    Pline = "%r %r %r 0 %r %r %r 0 0 0 1 0" % (K[0, 0], 0.0, K[0, 2], 0.0, K[1, 1], K[1, 2])
+    Pline = "%r %r %r 0 %r %r %r 0 0 0 1 0" % (float(K[0, 0]), 0.0, float(K[0, 2]), 0.0, float(K[1, 1]), float(K[1, 2]))
     with open(os.path.join(root, "sequences", seq, "calib.txt"), "w") as fh:
         for name in ("P0", "P1", "P2", "P3"):
             fh.write("%s: %s\n" % (name, Pline))
