@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pairs/s of the per-frame-pair hot path on N MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], batched): consecutive synthetic KITTI-shaped 1241x376 gray
+frames, ORB nfeatures=2000 detect+describe on every frame, brute-force Hamming 2-NN + ratio 0.7 +
+200 px gate between consecutive frames, findEssentialMat(RANSAC, 0.999, 1.0, seed (uint64)-1),
+recoverPose(200) — i.e. vo_pairs_run_dev().  A step = one pass over one batch of `--frames`
+frames (frames-1 frame pairs) that is already resident in HBM.  With N > 1 every rank runs its own
+synthetic sequence (sequences are the shard unit, no data-path collective; weak scaling) and the
+trajectories are gathered with one all_gather over RCCL after the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` is the matcher kernel under the O(N^2) scan model of
+SURVEY.md §8(d) (nq*nt*32 + nq*32 + nq*16 bytes per pair), timed live with HIP events on the
+library's stream; `cpu_baseline` is the CPU oracle (a port, single thread) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def scan_bytes(nq, nt):
+    return nq * nt * 32 + nq * 32 + nq * 16
+
+
+def cpu_baseline(frames, K, nfeatures, budget_s=12.0):
+    """The oracle's restatement of the same path, single thread, on the first pairs of the batch."""
+    from oracle import pyoracle as o
+
+    po = o.orb_params(nfeatures)
+    t0 = time.perf_counter()
+    k_prev, d_prev = o.orb_detect_compute(frames[0], po)
+    pairs = 0
+    for i in range(1, len(frames)):
+        k1, d1 = o.orb_detect_compute(frames[i], po)
+        knn, nv = o.knn2_hamming(d_prev, d1)
+        good = o.match_filter(knn, nv, k_prev, k1, 0.7, 200.0)
+        p0 = np.stack([k_prev["x"][good["queryIdx"]], k_prev["y"][good["queryIdx"]]], 1)
+        p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
+        rc, E, mask, _ = o.find_essential(p0, p1, K, o.RANSAC)
+        if rc == 0:
+            o.recover_pose(E, p0, p1, K, 200.0, mask)
+        k_prev, d_prev = k1, d1
+        pairs += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d frame pairs of the same batch (ORB on %d frames), oracle/ single thread" % (pairs, pairs + 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=33, help="frames per batch (pairs = frames - 1)")
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from visual_odometry_amd import api, synth
+
+    # ---- synthetic input: each rank renders its own sequence (the shard unit) ----------------
+    frames, poses, K = synth.make_sequence(rank, args.frames)
+    n, h, w = frames.shape
+    d_frames = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+
+    ctx = api.VoContext(local_rank, max_batch=max(64, args.frames))
+    params = api.pair_params(args.nfeatures)
+
+    def step():
+        return ctx.pairs_run_dev(d_frames.data_ptr(), n, w, h, w, w * h, K, params)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()  # synchronous on return: results are on the host
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    pairs_per_step = n - 1
+    total_pairs = world * args.steps * pairs_per_step
+
+    # ---- chain the relative poses into a trajectory on the host, gather over RCCL --------------
+    traj = np.zeros((n, 12))
+    R_w, t_w = np.eye(3), np.zeros(3)
+    traj[0] = np.hstack([R_w, t_w[:, None]]).reshape(-1)
+    for p in range(n - 1):
+        r = res[p]
+        if r.status == 0:
+            R = np.array(r.R).reshape(3, 3)
+            tt = np.array(r.t)
+            # reference convention (vo_pose.h:29-38): t = -t, R = R^T, unit scale here
+            t_w = t_w + R_w @ (-tt)
+            R_w = R.T @ R_w
+        traj[p + 1] = np.hstack([R_w, t_w[:, None]]).reshape(-1)
+    if dist is not None:
+        tj = torch.from_numpy(traj).to(dev)
+        out = [torch.empty_like(tj) for _ in range(world)]
+        dist.all_gather(out, tj)
+        torch.cuda.synchronize()
+
+    # ---- roofline: matcher kernel, HIP events on the library's stream (untimed passes) ----------
+    nkp = [res[0].n_kp0] + [res[p].n_kp1 for p in range(n - 1)]
+    algo_bytes = sum(scan_bytes(nkp[p], nkp[p + 1]) for p in range(n - 1))
+    ctx.prof_enable(True)
+    for which in (0, 1, 2):
+        ctx.prof_get(which, True)
+    for _ in range(5):
+        step()
+    knn_n, knn_ms = ctx.prof_get(0)
+    fast_n, fast_ms = ctx.prof_get(1)
+    solve_n, solve_ms = ctx.prof_get(2)
+    ctx.prof_enable(False)
+    knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
+    achieved = algo_bytes / knn_avg_s / 1e9 if knn_avg_s > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_knn2.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "k_knn2_partial<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "model": "O(N^2) scan model: nq*nt*32 + nq*32 + nq*16 bytes per pair (SURVEY.md 8d)",
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": knn_avg_s * 1e6,
+                "pairs_per_launch": n - 1}
+
+    # ---- 8k x 8k matcher (BASELINE config 3 shape), same accounting -----------------------------
+    matcher_8k = None
+    if rank == 0:
+        q, t = synth.matcher_descriptors(8192)
+        for _ in range(2):
+            ctx.knn2_hamming(q, t)
+        ctx.prof_enable(True)
+        ctx.prof_get(0, True)
+        for _ in range(5):
+            ctx.knn2_hamming(q, t)
+        kn, kms = ctx.prof_get(0)
+        ctx.prof_enable(False)
+        avg = kms / max(kn, 1) * 1e-3
+        b8 = scan_bytes(8192, 8192)
+        matcher_8k = {"avg_launch_us": avg * 1e6, "achieved_GBs": b8 / avg / 1e9,
+                      "frac_of_hbm_peak": b8 / avg / 1e9 / HBM_PEAK_GBS,
+                      "algorithmic_bytes": b8, "compulsory_bytes": (8192 + 8192) * 32 + 8192 * 16}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(frames, K, args.nfeatures)
+
+    if rank == 0:
+        ok = sum(1 for p in range(n - 1) if res[p].status == 0)
+        line = {
+            "metric": "frame-pairs/sec (1241x376, 2k ORB)",
+            "value": total_pairs / elapsed,
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 features/descriptors, u64 popcount matching, f64 geometry",
+            "data": "synthetic (seeded planar-world KITTI-shaped frames rendered by visual_odometry_amd/synth.py)",
+            "config": {"workload": "configs[1] batched: %d consecutive 1241x376 frames per GPU resident in HBM, "
+                                   "ORB nfeatures=%d + BF-Hamming knn2/ratio/gate + 5-pt RANSAC + recoverPose per "
+                                   "consecutive pair" % (n, args.nfeatures),
+                       "frames_per_step": n, "pairs_per_step": pairs_per_step, "nfeatures": args.nfeatures,
+                       "parallelism": "sequence shards x%d, no data-path collective" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "matcher_8k": matcher_8k,
+            "stage_us_per_step": {"fast_score_kernel": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
+                                  "knn2_partial_kernel": knn_avg_s * 1e6,
+                                  "solve5_kernels_per_step": solve_ms / 5 * 1e3},
+            "pairs_with_pose": ok,
+            "keypoints_per_frame": float(np.mean(nkp)),
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

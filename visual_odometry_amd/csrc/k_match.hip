@@ -76,13 +76,17 @@ __global__ __launch_bounds__(256) void k_knn2_merge(KnnArgs a) {
     a.knn[(size_t)pair * a.nq_cap + qi] = make_uint2(k1, k2);
 }
 
-void launch_knn2(hipStream_t st, const KnnArgs& a) {
+void launch_knn2_partial(hipStream_t st, const KnnArgs& a) {
     if (a.nq <= 0 || a.npairs <= 0) return;
     dim3 grid(cdiv(a.nq, 256), a.splits, a.npairs);
     if (a.words == 8)
         hipLaunchKernelGGL(k_knn2_partial<4>, grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(k_knn2_partial<8>, grid, dim3(256), 0, st, a);
+}
+
+void launch_knn2_merge(hipStream_t st, const KnnArgs& a) {
+    if (a.nq <= 0 || a.npairs <= 0) return;
     hipLaunchKernelGGL(k_knn2_merge, dim3(cdiv(a.nq, 256), a.npairs), dim3(256), 0, st, a);
 }
 

@@ -89,7 +89,8 @@ struct KnnArgs {
     int nq_cap;
     int npairs;
 };
-void launch_knn2(hipStream_t st, const KnnArgs& a);
+void launch_knn2_partial(hipStream_t st, const KnnArgs& a);
+void launch_knn2_merge(hipStream_t st, const KnnArgs& a);
 
 struct GoodMatch {
     int q, t, dist, pad;

@@ -32,8 +32,9 @@ int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q
     a.knn = c->d_knn.as<uint2>();
     {
         ProfScope ps(c, VO_PROF_KNN);
-        launch_knn2(c->stream, a);
+        launch_knn2_partial(c->stream, a);
     }
+    launch_knn2_merge(c->stream, a);
     return vo_check_launch(c, "knn2");
 }
 
