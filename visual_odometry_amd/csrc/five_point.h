@@ -22,6 +22,13 @@
 
 #define FP_SCRATCH 236  // 10x20 constraint matrix + 4x9 null-space basis
 
+// reciprocal for Newton steps (the step only has to be roughly right; the root is fixed by f)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VO_RCP(x) __builtin_amdgcn_rcp(x)
+#else
+#define VO_RCP(x) (1.0 / (x))
+#endif
+
 namespace fp_detail {
 
 VO_HD void mul_ll_acc(const double* a, const double* b, double* q, double sgn) {
@@ -60,8 +67,10 @@ VO_HD void horner(const double (&a)[D + 1], double x, double& f, double& df) {
 }
 
 // root of a (degree D) inside [lo, hi] given a sign change; safeguarded Newton / bisection
+// `tol`: relative step size at which the iteration stops.  Only the roots of c itself need full
+// precision; the roots of its derivatives merely bracket them.
 template <int D>
-VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double flo) {
+VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double flo, double tol) {
     double xl, xh;
     if (flo < 0) {
         xl = lo;
@@ -81,12 +90,12 @@ VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double
             if (xl == rts) break;
         } else {
             dxold = dx;
-            dx = f / df;
+            dx = f * VO_RCP(df);
             const double temp = rts;
             rts -= dx;
             if (temp == rts) break;
         }
-        if (fabs(dx) <= 4e-16 * fabs(rts)) break;
+        if (fabs(dx) <= tol * fabs(rts)) break;
         horner<D>(a, rts, f, df);
         if (f < 0) xl = rts;
         else xh = rts;
@@ -109,7 +118,7 @@ VO_HD int level_roots(const double (&c)[11], double bound, int nprev, const S& s
         double fhi;
         horner<D>(a, hi, fhi, d);
         if ((flo < 0) != (fhi < 0)) {
-            s(cur + ncur) = bracket_root<D>(a, lo, hi, flo);
+            s(cur + ncur) = bracket_root<D>(a, lo, hi, flo, D == 10 ? 4e-16 : 1e-9);
             ncur++;
         }
         lo = hi;

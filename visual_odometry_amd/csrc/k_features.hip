@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_nms_rows(FrameSrc src, const PyrGeom* __
                     cd.y = (int16_t)y;
                     cd.level = (int16_t)l;
                     cd.score = (int16_t)s;
-                    cd.harris = harris ? harris_response(img, ipitch, x, y) : 0.f;
+                    cd.harris = 0.f;  // filled by k_harris (one thread per candidate)
                     cd.pad = 0;
                     cand[(size_t)f * max_cand + pos] = cd;
                 }
@@ -262,6 +262,20 @@ __global__ __launch_bounds__(64) void k_nms_rows(FrameSrc src, const PyrGeom* __
         }
     }
     if (!WRITE && lane == 0) rowcnt[(size_t)f * g->rows_total + row] = total;
+}
+
+// Harris response of every candidate (ORB): one thread per candidate, dense over the list.
+__global__ __launch_bounds__(256) void k_harris(FrameSrc src, const PyrGeom* __restrict__ g,
+                                                const int* __restrict__ lvlofs, Cand* __restrict__ cand,
+                                                int max_cand) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + g->nlevels], max_cand);
+    if (i >= total) return;
+    Cand* c = cand + (size_t)f * max_cand + i;
+    int pitch;
+    const uint8_t* img = level_base(src, g, f, c->level, pitch);
+    c->harris = harris_response(img, pitch, c->x, c->y);
 }
 
 // Exclusive scan of the per-row counts of one frame (one block per frame) -> rowofs[rows+1],
@@ -495,6 +509,12 @@ void launch_nms_write(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom
     dim3 grid(hg.rows_total, nframes);
     hipLaunchKernelGGL(k_nms_rows<true>, grid, dim3(64), 0, st, src, d_geom, score, border, nms, harris,
                        (int*)nullptr, rowofs, cand, max_cand);
+}
+
+void launch_harris(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
+                   int max_cand, int grid_cand, int nframes) {
+    dim3 grid(cdiv(grid_cand, 256), nframes);
+    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, st, src, d_geom, lvlofs, cand, max_cand);
 }
 
 void launch_ic_angle(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const Cand* sel,

@@ -20,9 +20,10 @@
 
 namespace {
 
+template <int LANES>
 struct LaneScratch {
-    double* base;  // lds + lane; element i at base[64 i]
-    __device__ __forceinline__ double& operator()(int i) const { return base[i * 64]; }
+    double* base;  // lds + lane; element i at base[LANES i]
+    __device__ __forceinline__ double& operator()(int i) const { return base[i * LANES]; }
 };
 
 __device__ __forceinline__ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
@@ -78,14 +79,17 @@ __global__ __launch_bounds__(256) void k_normalize(const float2* __restrict__ p0
     x2[o] = make_double2(((double)b.x - k.cx) / k.fx, ((double)b.y - k.cy) / k.fy);
 }
 
-__global__ __launch_bounds__(64) void k_solve5(int h0, int h1, const EstState* __restrict__ st,
+// LANES hypotheses per block (one partially filled wave when LANES < 64): small launches use few
+// lanes per wave so that the hypotheses spread over many CUs and diverge less.
+template <int LANES>
+__global__ __launch_bounds__(LANES) void k_solve5(int h0, int h1, const EstState* __restrict__ st,
                                                const uint16_t* __restrict__ samples, int samples_iters,
                                                const double2* __restrict__ x1, const double2* __restrict__ x2,
                                                int n_cap, double* __restrict__ models, int* __restrict__ nmodels,
                                                int H) {
-    __shared__ double lds[FP_SCRATCH * 64];
+    __shared__ double lds[FP_SCRATCH * LANES];
     const int pair = blockIdx.y, lane = threadIdx.x;
-    const int hb = h0 + blockIdx.x * 64;
+    const int hb = h0 + blockIdx.x * LANES;
     const int cap = min(h1, st[pair].niters);
     if (hb >= cap) return;
     const int h = hb + lane;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(64) void k_solve5(int h0, int h1, const EstState* _
         b[2 * k] = v.x;
         b[2 * k + 1] = v.y;
     }
-    LaneScratch s{lds + lane};
+    LaneScratch<LANES> s{lds + lane};
     const size_t slot = (size_t)pair * H + h;
     nmodels[slot] = five_point_solve(a, b, s, models + slot * 90);
 }
@@ -493,8 +497,19 @@ void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const 
 void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
                    const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H,
                    int npairs) {
-    hipLaunchKernelGGL(k_solve5, dim3(cdiv(h1 - h0, 64), npairs), dim3(64), 0, st, h0, h1, s, samples, samples_iters,
-                       x1, x2, n_cap, models, nmodels, H);
+    int lanes = 64;
+    while (lanes > 4 && (long)(h1 - h0) * npairs / lanes < 1024) lanes /= 2;
+#define VO_SOLVE5(L)                                                                                           \
+    hipLaunchKernelGGL(k_solve5<L>, dim3(cdiv(h1 - h0, L), npairs), dim3(L), 0, st, h0, h1, s, samples, samples_iters, \
+                       x1, x2, n_cap, models, nmodels, H)
+    switch (lanes) {
+        case 4: VO_SOLVE5(4); break;
+        case 8: VO_SOLVE5(8); break;
+        case 16: VO_SOLVE5(16); break;
+        case 32: VO_SOLVE5(32); break;
+        default: VO_SOLVE5(64); break;
+    }
+#undef VO_SOLVE5
 }
 
 void launch_score(hipStream_t st, int h0, int h1, const EstState* s, const double2* x1, const double2* x2, int n_cap,

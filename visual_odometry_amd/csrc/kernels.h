@@ -64,6 +64,8 @@ void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const int* rowcnt, i
 void launch_nms_write(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
                       const uint8_t* score, int border, int nms, int harris, const int* rowofs,
                       Cand* cand, int max_cand, int nframes);
+void launch_harris(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
+                   int max_cand, int grid_cand, int nframes);
 void launch_ic_angle(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const Cand* sel,
                      const int* nkp, int kp_cap, int max_n, vo_keypoint* out, int nframes);
 void launch_gauss7(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,

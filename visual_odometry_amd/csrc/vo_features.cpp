@@ -5,6 +5,7 @@
 // Replaces FeatureDetector's cv calls (reference: src/features/feature_detector.cpp:3-42).
 #include <algorithm>
 #include <cmath>
+#include <thread>
 
 #include "ctx.h"
 
@@ -212,6 +213,8 @@ int feat_detect(vo_ctx* c, const FrameSrc& src_in, int nframes, int fast_thresho
     launch_row_scan(st, dg, c->d_rowcnt.as<int>(), c->d_rowofs.as<int>(), c->d_lvlofs.as<int>(), nframes);
     launch_nms_write(st, src, dg, g, c->d_score.as<uint8_t>(), border, nms, harris, c->d_rowofs.as<int>(),
                      c->d_cand.as<Cand>(), c->max_cand, nframes);
+    if (harris)
+        launch_harris(st, src, dg, c->d_lvlofs.as<int>(), c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
     VO_TRY(vo_check_launch(c, "feature detection"));
     const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
     VO_HIP(c, hipMemcpyAsync(c->h_lvlofs.p, c->d_lvlofs.p, lv_bytes, hipMemcpyDeviceToHost, st));
@@ -237,9 +240,8 @@ int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out) {
     const PyrGeom& g = c->geom;
     const int* lv = c->h_lvlofs.as<int>();
     int* nkp = c->h_nkp.as<int>();
-    std::vector<RespIdx> v;
-    int max_n = 0;
-    for (int f = 0; f < nframes; f++) {
+    // frames are independent: the (sequential, libstdc++-defined) selections run on host threads
+    auto select_frame = [&](int f, std::vector<RespIdx>& v) -> int {
         const Cand* cand = c->h_cand.as<Cand>() + (size_t)f * c->max_cand;
         Cand* sel = c->h_sel.as<Cand>() + (size_t)f * c->kp_cap;
         int n = 0;
@@ -250,14 +252,32 @@ int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out) {
             retain_best(v, 2 * c->quota[l]);
             for (auto& r : v) r.response = cand[r.idx].harris;
             retain_best(v, c->quota[l]);
-            if (n + (int)v.size() > c->kp_cap)
-                return c->fail(VO_ERR_CAPACITY, "frame %d selects more than %d keypoints", f, c->kp_cap);
+            if (n + (int)v.size() > c->kp_cap) return -1;
             for (auto& r : v) sel[n++] = cand[r.idx];
         }
-        nkp[f] = n;
+        return n;
+    };
+    const int nthreads = std::max(1, std::min({nframes, 16, (int)std::thread::hardware_concurrency()}));
+    if (nthreads == 1) {
+        std::vector<RespIdx> v;
+        for (int f = 0; f < nframes; f++) nkp[f] = select_frame(f, v);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t]() {
+                std::vector<RespIdx> v;
+                for (int f = t; f < nframes; f += nthreads) nkp[f] = select_frame(f, v);
+            });
+        for (auto& th : pool) th.join();
+    }
+    int max_n = 0;
+    for (int f = 0; f < nframes; f++) {
+        const int n = nkp[f];
+        if (n < 0) return c->fail(VO_ERR_CAPACITY, "frame %d selects more than %d keypoints", f, c->kp_cap);
         max_n = std::max(max_n, n);
         if (n > 0)
-            VO_HIP(c, hipMemcpyAsync(c->d_sel.as<Cand>() + (size_t)f * c->kp_cap, sel, (size_t)n * sizeof(Cand),
+            VO_HIP(c, hipMemcpyAsync(c->d_sel.as<Cand>() + (size_t)f * c->kp_cap,
+                                     c->h_sel.as<Cand>() + (size_t)f * c->kp_cap, (size_t)n * sizeof(Cand),
                                      hipMemcpyHostToDevice, c->stream));
     }
     nkp[nframes] = 0;
