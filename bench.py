@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--frames", type=int, default=33, help="frames per batch (pairs = frames - 1)")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
     args = ap.parse_args()
 
     import torch
@@ -81,7 +82,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from visual_odometry_amd import api, synth
+    from visual_odometry_amd import api, shard, synth
 
     # ---- synthetic input: each rank renders its own sequence (the shard unit) ----------------
     frames, poses, K = synth.make_sequence(rank, args.frames)
@@ -116,23 +117,11 @@ def main():
     total_pairs = world * args.steps * pairs_per_step
 
     # ---- chain the relative poses into a trajectory on the host, gather over RCCL --------------
-    traj = np.zeros((n, 12))
-    R_w, t_w = np.eye(3), np.zeros(3)
-    traj[0] = np.hstack([R_w, t_w[:, None]]).reshape(-1)
-    for p in range(n - 1):
-        r = res[p]
-        if r.status == 0:
-            R = np.array(r.R).reshape(3, 3)
-            tt = np.array(r.t)
-            # reference convention (vo_pose.h:29-38): t = -t, R = R^T, unit scale here
-            t_w = t_w + R_w @ (-tt)
-            R_w = R.T @ R_w
-        traj[p + 1] = np.hstack([R_w, t_w[:, None]]).reshape(-1)
+    traj = shard.chain_poses([(res[p].status, np.array(res[p].R), np.array(res[p].t)) for p in range(n - 1)], n)
     if dist is not None:
-        tj = torch.from_numpy(traj).to(dev)
-        out = [torch.empty_like(tj) for _ in range(world)]
-        dist.all_gather(out, tj)
+        all_traj = shard.gather_trajectories({rank: traj}, dist, dev)
         torch.cuda.synchronize()
+        assert len(all_traj) == world
 
     # ---- roofline: matcher kernel, HIP events on the library's stream (untimed passes) ----------
     nkp = [res[0].n_kp0] + [res[p].n_kp1 for p in range(n - 1)]
@@ -149,10 +138,11 @@ def main():
     knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
     achieved = algo_bytes / knn_avg_s / 1e9 if knn_avg_s > 0 else 0.0
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_knn2.json")
+    # HBM bytes per launch from the committed PMC passes (tools/gpu_profile.sh -> profiles/)
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc_path))["kernels"]["k_knn2_partial<4>"]["hbm_bytes"]
         except Exception:
             traffic = None
     roofline = {"kernel": "k_knn2_partial<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -163,7 +153,7 @@ def main():
 
     # ---- 8k x 8k matcher (BASELINE config 3 shape), same accounting -----------------------------
     matcher_8k = None
-    if rank == 0:
+    if rank == 0 and not args.no_8k:
         q, t = synth.matcher_descriptors(8192)
         for _ in range(2):
             ctx.knn2_hamming(q, t)
