@@ -155,6 +155,24 @@ int vo_pairs_get_matches(vo_ctx* ctx, int pair, vo_dmatch* good, uint8_t* inlier
 #define VO_PROF_SOLVE 2
 #define VO_PROF_COUNT 3
 int vo_prof_enable(vo_ctx* ctx, int on);
+
+/* Tuning / test knobs of a context (no reference counterpart).
+ * VO_OPT_SEL_CAP: candidates per (frame, level) the device-side keypoint selection holds in LDS
+ * (default 6144, at most 13000); a level with more candidates is selected on the host instead,
+ * with identical results.  Tests set it low to exercise that path.
+ * VO_OPT_LAST_FLAGS (read with vo_ctx_get_option): OR of the selection flags of the last batch
+ * (0 = every frame was selected on the device). */
+#define VO_OPT_SEL_CAP 0
+#define VO_OPT_LAST_FLAGS 1
+int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
+int vo_ctx_get_option(vo_ctx* ctx, int option, int* value);
+
+/* Test hook (no reference counterpart): copies level `level` of frame `frame` of the last ORB call's
+ * pyramid (which = VO_DBG_PYRAMID: cv::resize INTER_LINEAR_EXACT chain) or blurred pyramid
+ * (VO_DBG_BLUR: GaussianBlur 7x7 sigma 2) to `out` as w x h tightly packed bytes. */
+#define VO_DBG_PYRAMID 0
+#define VO_DBG_BLUR 1
+int vo_debug_read_level(vo_ctx* ctx, int which, int frame, int level, uint8_t* out, int cap, int* w, int* h);
 int vo_prof_get(vo_ctx* ctx, int which, int reset, int* launches, double* total_ms);
 
 #ifdef __cplusplus

@@ -135,3 +135,69 @@ def test_orb_stress_8k(vo, oracle, frames):
     kg, dg = vo.orb_detect_compute(fr[0], api.orb_params(8192), cap=20000)
     ko, do = oracle.orb_detect_compute(fr[0], oracle.orb_params(8192))
     assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+
+
+def test_orb_device_selection_is_used_and_host_path_agrees(oracle, frames):
+    """The keypoint selection (retainBest = nth_element + partition, whose permutation fixes the
+    keypoint order) runs on the device; a context with a tiny selection buffer is forced through
+    the host path.  Both must give the oracle's keypoints in the oracle's order."""
+    from visual_odometry_amd import api
+
+    fr = frames[0]
+    ko, do = oracle.orb_detect_compute(fr[0], oracle.orb_params(2000))
+    ctx = api.VoContext(0)
+    try:
+        kg, dg = ctx.orb_detect_compute(fr[0], api.orb_params(2000))
+        assert ctx.get_option(api.OPT_LAST_FLAGS) == 0
+        assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+        ctx.set_option(api.OPT_SEL_CAP, 64)
+        kh, dh = ctx.orb_detect_compute(fr[0], api.orb_params(2000))
+        assert ctx.get_option(api.OPT_LAST_FLAGS) & 1
+        assert np.array_equal(kh, ko) and np.array_equal(dh, do)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_orb_periodic_image_response_ties(oracle, seed):
+    """A periodic texture gives many keypoints with identical FAST scores and Harris responses: the
+    ties exercise the equal-key behaviour of the Hoare partition and of partition(>= ambiguous) in
+    the device-side selection (asserted to be the path taken)."""
+    from visual_odometry_amd import api
+
+    rng = np.random.default_rng(seed)
+    cell = rng.integers(0, 256, (94, 106)).astype(np.float32)
+    for _ in range(16):
+        cell = (cell + np.roll(cell, 1, 0) + np.roll(cell, -1, 0) + np.roll(cell, 1, 1) + np.roll(cell, -1, 1)) / 5
+    cell = np.clip((cell - cell.mean()) * 4.0 + 128, 0, 255).astype(np.uint8)
+    img = np.tile(cell, (4, 12))[:376, :1241].copy()
+    img[100:140, 300:360] = rng.integers(0, 256, (40, 60), dtype=np.uint8)  # break the symmetry a little
+    ctx = api.VoContext(0)
+    try:
+        ctx.set_option(api.OPT_SEL_CAP, 13000)
+        for nf in (500, 2000):
+            kg, dg = ctx.orb_detect_compute(img, api.orb_params(nf), cap=40000)
+            ko, do = oracle.orb_detect_compute(img, oracle.orb_params(nf))
+            if nf == 2000:  # tied responses at the cut: more than nfeatures keypoints are kept
+                assert len(ko) > nf and len(np.unique(ko["response"])) < len(ko)
+            assert ctx.get_option(api.OPT_LAST_FLAGS) == 0
+            assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    finally:
+        ctx.close()
+
+
+def test_orb_pyramid_and_blur_levels(vo, oracle, frames):
+    """Intermediate images of the ORB path, level by level: the INTER_LINEAR_EXACT resize chain and
+    the 7x7 fixed-point Gaussian blur, bit-exact against the oracle."""
+    from visual_odometry_amd import api
+
+    fr = frames[0]
+    vo.orb_detect_compute(fr[2], api.orb_params(2000))
+    po = oracle.orb_params(2000)
+    for level in range(8):
+        for which, blurred in ((0, False), (1, True)):
+            g = vo.debug_read_level(which, 0, level)
+            o = oracle.orb_level(fr[2], po, level, blurred=blurred)
+            assert g.shape == o.shape
+            assert np.array_equal(g, o), "level %d %s: %d pixels differ" % (
+                level, "blur" if blurred else "pyramid", int((g != o).sum()))

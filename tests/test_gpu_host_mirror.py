@@ -49,7 +49,20 @@ def test_host_mirror_matches_oracle(tmp_path, oracle):
     p1 = np.stack([ko[1][0]["x"][good["trainIdx"]], ko[1][0]["y"][good["trainIdx"]]], 1)
     rc, E_r, mask_r, _ = oracle.find_essential(p0, p1, K, oracle.RANSAC)
     assert rc == 0 and np.array_equal(load("inliers.bin", np.uint8), mask_r)
-    assert load("ntracks.bin", np.int32)[0] == int(mask_r.sum())  # 1:1 matches -> one track per inlier
+    # createMatchMatrix (reference: src/matcher/matcher.cpp:55-86): an inlier match joins the first track
+    # that already holds either of its ends
+    tracks = []
+    for m, keep in zip(good, mask_r):
+        if keep != 1:
+            continue
+        q, t = int(m["queryIdx"]), int(m["trainIdx"])
+        for row in tracks:
+            if row[0] == q or row[1] == t:
+                row[0], row[1] = q, t
+                break
+        else:
+            tracks.append([q, t])
+    assert load("ntracks.bin", np.int32)[0] == len(tracks)
     # updatePose(): findEssentialMat(LMEDS) + recoverPose + sign/transpose convention + chaining
     rc, E, mask, _ = oracle.find_essential(p0, p1, K, oracle.LMEDS)
     ng, R, t, pm, pts4 = oracle.recover_pose(E, p0, p1, K, 200.0, mask)

@@ -17,7 +17,7 @@ SYMBOLS = [
     "vo_orb_params_default", "vo_fast_detect", "vo_orb_detect_compute", "vo_orb_compute",
     "vo_knn2_hamming", "vo_match_filter", "vo_find_essential", "vo_recover_pose", "vo_triangulate",
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
-    "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get",
+    "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
 ]
 
 

@@ -17,6 +17,7 @@ KP_DTYPE = np.dtype(
 DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
 
 LMEDS, RANSAC = 4, 8
+OPT_SEL_CAP, OPT_LAST_FLAGS = 0, 1
 VO_OK, VO_ERR_INVALID, VO_ERR_CAPACITY, VO_ERR_DEVICE, VO_ERR_FAILED = 0, 1, 2, 3, 4
 
 
@@ -216,6 +217,24 @@ class VoContext:
         n = C.c_int(0)
         self._check(self.L.vo_pairs_get_matches(self.h, int(pair), _p(good), _p(m1), _p(m2), cap, C.byref(n)))
         return good[: n.value].copy(), m1[: n.value].copy(), m2[: n.value].copy()
+
+    # ---- knobs ---------------------------------------------------------------------------
+    def set_option(self, option, value):
+        self._check(self.L.vo_ctx_set_option(self.h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int(0)
+        self._check(self.L.vo_ctx_get_option(self.h, int(option), C.byref(v)))
+        return v.value
+
+    def debug_read_level(self, which, frame, level):
+        """Level `level` of the last ORB call's pyramid (which=0) or blurred pyramid (which=1)."""
+        cap = self.limits.max_width * self.limits.max_height
+        out = np.zeros(cap, np.uint8)
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self.L.vo_debug_read_level(self.h, int(which), int(frame), int(level), _p(out), cap,
+                                               C.byref(w), C.byref(h)))
+        return out[: w.value * h.value].reshape(h.value, w.value).copy()
 
     # ---- measurement hooks ---------------------------------------------------------------
     def prof_enable(self, on=True):

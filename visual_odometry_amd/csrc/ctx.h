@@ -44,21 +44,26 @@ struct vo_ctx {
 
     // ---- feature workspace (per frame strides: geom.pyr_bytes, max_cand, kp_cap) ---------
     DevBuf d_img;     // uploaded frames (host-pointer entry points)
-    DevBuf d_pyr;     // packed pyramid levels >= 1
+    DevBuf d_pyr;     // packed padded pyramid, all levels (level 0 = copy of the caller's frame)
     DevBuf d_blur;    // blurred pyramid, all levels
-    DevBuf d_score;   // FAST score map, all levels
-    DevBuf d_rowcnt;  // int [frame][rows_total]
-    DevBuf d_rowofs;  // int [frame][rows_total + 1]
+    DevBuf d_score;   // FAST score + 1 at keypoint positions (sparsely written), pyramid layout
+    DevBuf d_masks;   // uint64 [frame][segs_total]: keypoint bit per pixel, one word per 64-pixel row segment
+    DevBuf d_segbase; // int [frame][segs_total]: candidate-list position of each segment's first keypoint
     DevBuf d_lvlofs;  // int [frame][VO_ORB_MAX_LEVELS + 1]
-    DevBuf d_cand;    // Cand [frame][max_cand]
-    DevBuf d_sel;     // Cand [frame][kp_cap]: keypoints selected on the host
+    DevBuf d_cand;    // Cand [frame][max_cand]: row-major candidates, level after level
+    DevBuf d_selidx;  // int [frame][max_cand]: device selection, level l's picks at lvlofs[l]
+    DevBuf d_selcnt;  // int [frame][VO_ORB_MAX_LEVELS]
+    DevBuf d_flags;   // int [frame]: VO_SEL_* flags of the device selection
+    DevBuf d_sel;     // Cand [frame][kp_cap]: keypoints selected on the host (fallback path)
     DevBuf d_coef;    // resize coefficient tables
     DevBuf d_geom;    // PyrGeom
     DevBuf d_kp;      // vo_keypoint [frame][kp_cap]
     DevBuf d_desc;    // uint8 [frame][kp_cap][32]
     DevBuf d_nkp;     // int [frame] (+1 spare)
-    PinnedBuf h_lvlofs, h_cand, h_sel, h_nkp, h_misc;
+    PinnedBuf h_lvlofs, h_cand, h_sel, h_nkp, h_misc, h_flags;
     int max_cand = 65536;
+    int last_flags = 0;  // OR of the VO_SEL_* flags of the last batch
+    int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
     int kp_cap = 0;
     int feat_frames = 0;
 
@@ -133,10 +138,15 @@ int vo_check_launch(vo_ctx* ctx, const char* what);
 
 // features (vo_features.cpp)
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);
-int feat_detect(vo_ctx* c, const FrameSrc& src, int nframes, int fast_threshold, int border, int nms,
-                int harris);
-int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out);
-int feat_describe(vo_ctx* c, const FrameSrc& src, int nframes, int max_n, bool angles);
+int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes, int fast_threshold,
+                int border, int nms);
+int feat_fetch_cands(vo_ctx* c, int nframes);
+int feat_select_dev(vo_ctx* c, int nframes, int n_bound);
+int feat_select_host(vo_ctx* c, int nframes, int* max_n_out);
+int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_selection);
+int feat_n_bound(const vo_ctx* c, int nfeatures);
+int feat_orb_frames(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes,
+                    const vo_orb_params* p, int* max_n_out);
 
 // geometry (vo_geometry.cpp)
 struct EstArgs;

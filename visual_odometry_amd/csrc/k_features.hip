@@ -1,35 +1,20 @@
-// k_features.hip — gfx950 kernels for FAST-9/16 and ORB (pyramid, FAST score, NMS + ordered
-// compaction + Harris, IC angle, 7x7 blur, rBRIEF).  Integer pipeline throughout; the few float
-// expressions (Harris epilogue, fastAtan2, pattern rotation) follow cv's operation order and
-// the file is compiled with -ffp-contract=off so nothing is fused.
-// Behaviour follows SURVEY.md A.1/A.2; reference call sites: src/features/feature_detector.cpp:4-5,15,24,28,41.
+// k_features.hip — gfx950 kernels for FAST-9/16 and ORB: padded pyramid, fused FAST score + NMS
+// tiles, ordered candidate lists, device-side keypoint selection (cv's retainBest with libstdc++'s
+// nth_element / partition permutation reproduced on a wavefront), IC angle, 7x7 blur, rBRIEF.
+// Integer pipeline throughout; the few float expressions (Harris epilogue, fastAtan2, pattern
+// rotation) follow cv's operation order and the file is compiled with -ffp-contract=off so nothing
+// is fused.  Behaviour follows SURVEY.md A.1/A.2; reference call sites:
+// src/features/feature_detector.cpp:4-5,15,24,28,41.
 #include "kernels.h"
 
 namespace {
 
-__device__ __forceinline__ const uint8_t* level_base(const FrameSrc& s, const PyrGeom* g, int f, int l,
-                                                     int& pitch) {
-    if (l == 0) {
-        pitch = s.stride;
-        return s.img + (size_t)f * s.frame_stride;
-    }
-    pitch = g->lv[l].pitch;
-    return s.pyr + (size_t)f * g->pyr_bytes + g->lv[l].offset;
+// pointer to pixel (0,0) of level l of frame f in a packed buffer
+__device__ __forceinline__ const uint8_t* level_px(const uint8_t* buf, const PyrGeom* g, int f, int l) {
+    return buf + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)VO_PADY * g->lv[l].pitch + VO_PADX;
 }
-
-__device__ __forceinline__ int find_level_by_tile(const PyrGeom* g, int tile, int& local) {
-    int l = 0;
-    for (int i = 1; i < g->nlevels; i++)
-        if (tile >= g->tile_start[i]) l = i;
-    local = tile - g->tile_start[l];
-    return l;
-}
-
-__device__ __forceinline__ int find_level_by_row(const PyrGeom* g, int row) {
-    int l = 0;
-    for (int i = 1; i < g->nlevels; i++)
-        if (row >= g->lv[i].row0) l = i;
-    return l;
+__device__ __forceinline__ uint8_t* level_px(uint8_t* buf, const PyrGeom* g, int f, int l) {
+    return buf + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)VO_PADY * g->lv[l].pitch + VO_PADX;
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -38,154 +23,384 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// Pyramid level l from level l-1: cv::resize(INTER_LINEAR_EXACT), 8.8 fixed-point coefficients
-// from host tables (xtab/ytab entries: ofs << 16 | c1, c0 = 256 - c1).
+// Level 0: copy of the caller's image into the padded layout, with the 3-pixel reflect-101 frame.
+// One thread per aligned dword of the destination.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_resize(FrameSrc src, const PyrGeom* __restrict__ g,
-                                                    uint8_t* __restrict__ pyr, int level,
-                                                    const uint32_t* __restrict__ xtab,
-                                                    const uint32_t* __restrict__ ytab) {
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
+                                                    const PyrGeom* __restrict__ g, uint8_t* __restrict__ pyr) {
     const int f = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int dw = g->lv[level].w, dh = g->lv[level].h;
-    if (x >= dw || y >= dh) return;
-    const int sw = g->lv[level - 1].w, sh = g->lv[level - 1].h;
-    int spitch;
-    const uint8_t* s = level_base(src, g, f, level - 1, spitch);
-    const uint32_t tx = xtab[x], ty = ytab[y];
-    const int ox = tx >> 16, cx1 = tx & 0xffff, cx0 = 256 - cx1;
-    const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
-    const int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
-    const uint8_t* r0 = s + (size_t)oy * spitch;
-    const uint8_t* r1 = s + (size_t)oy1 * spitch;
-    const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-    const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
-    const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
-    pyr[(size_t)f * g->pyr_bytes + g->lv[level].offset + (size_t)y * g->lv[level].pitch + x] =
-        (uint8_t)min(v, 255u);
+    const int w = g->lv[0].w, h = g->lv[0].h, pitch = g->lv[0].pitch;
+    const int x4 = -4 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = -3 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= w + 3 || y >= h + 3) return;
+    const uint8_t* src = img + (size_t)f * frame_stride + (size_t)reflect101(y, h) * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (uint32_t)src[reflect101(x4 + j, w)] << (8 * j);
+    uint8_t* dst = level_px(pyr, g, f, 0);
+    *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * pitch + x4) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST-9/16 corner test + cornerScore<16> for every pixel of every level.  One block = a
-// 64 x 16 pixel tile staged in LDS with a 3-pixel halo.  Output map: 0 = not a corner,
-// score + 1 otherwise (score <= 254).
+// Pyramid level l from level l-1: cv::resize(INTER_LINEAR_EXACT), 8.8 fixed-point coefficients
+// from host tables (xtab/ytab entries: ofs << 16 | c1, c0 = 256 - c1).  The reflect-101 frame of
+// the new level is produced by evaluating the resize at the reflected coordinate.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(const PyrGeom* __restrict__ g, uint8_t* __restrict__ pyr,
+                                                    int level, const uint32_t* __restrict__ xtab,
+                                                    const uint32_t* __restrict__ ytab) {
+    const int f = blockIdx.z;
+    const int dw = g->lv[level].w, dh = g->lv[level].h, dpitch = g->lv[level].pitch;
+    const int x4 = -4 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = -3 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= dw + 3 || y >= dh + 3) return;
+    const int sw = g->lv[level - 1].w, sh = g->lv[level - 1].h, spitch = g->lv[level - 1].pitch;
+    const uint8_t* s = level_px((const uint8_t*)pyr, g, f, level - 1);
+    const uint32_t ty = ytab[reflect101(y, dh)];
+    const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
+    const int oy1 = min(oy + 1, sh - 1);
+    const uint8_t* r0 = s + (size_t)oy * spitch;
+    const uint8_t* r1 = s + (size_t)oy1 * spitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t tx = xtab[reflect101(x4 + j, dw)];
+        const int ox = tx >> 16, cx1 = tx & 0xffff, cx0 = 256 - cx1;
+        const int ox1 = min(ox + 1, sw - 1);
+        const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
+        const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+        const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
+        out |= min(v, 255u) << (8 * j);
+    }
+    uint8_t* dst = level_px(pyr, g, f, level);
+    *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 + cornerScore<16> + 3x3 strict-greater NMS + border filter, fused per 64 x 32 tile.
+//   phase 0  tile pixels (+4 halo) -> LDS with aligned dword loads
+//   phase A  compass test (ring points 0,4,8,12: a 9-arc holds two adjacent ones) on every pixel
+//            of the 66 x 34 score region; survivors (about one pixel in eight) are compacted
+//   phase B  full 16-point arc test on the survivors, dense lanes; corners are compacted again
+//   phase C  cornerScore of the corners -> LDS score map (score + 1, 0 = not a corner)
+//   phase D  NMS + border filter of the corners inside the tile -> per-row 64-bit masks in LDS,
+//            score byte of each keypoint -> sparse global score map
+//   phase E  one 64-bit mask per tile row -> global mask table
+// Row-major keypoint order (what cv's FAST emits) is rebuilt from the masks by k_row_scan /
+// k_cand_write.
 // ---------------------------------------------------------------------------------------------
 #define FT_W 64
-#define FT_H 16
-__global__ __launch_bounds__(256) void k_fast_score(FrameSrc src, const PyrGeom* __restrict__ g,
-                                                    uint8_t* __restrict__ score, int threshold) {
-    __shared__ uint8_t tile[FT_H + 6][FT_W + 8];
-    const int f = blockIdx.y;
-    int local;
-    const int l = find_level_by_tile(g, blockIdx.x, local);
-    const int w = g->lv[l].w, h = g->lv[l].h;
-    const int tiles_x = (w + FT_W - 1) / FT_W;
-    const int tx0 = (local % tiles_x) * FT_W, ty0 = (local / tiles_x) * FT_H;
-    int pitch;
-    const uint8_t* img = level_base(src, g, f, l, pitch);
+#define FT_H 32
+#define SM_W (FT_W + 2)
+#define SM_H (FT_H + 2)
+#define PX_W (FT_W + 8)
+#define PX_H (FT_H + 8)
 
-    for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-        const int r = i / (FT_W + 6), c = i - r * (FT_W + 6);
-        const int gx = min(max(tx0 + c - 3, 0), w - 1), gy = min(max(ty0 + r - 3, 0), h - 1);
-        tile[r][c] = img[(size_t)gy * pitch + gx];
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
+                                                  uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
+                                                  int threshold, int border, int nms) {
+    __shared__ uint32_t px4[PX_H * (PX_W / 4)];
+    __shared__ uint8_t sm[SM_H][SM_W + 2];
+    __shared__ uint16_t listA[SM_W * SM_H];
+    __shared__ uint16_t listB[SM_W * SM_H];
+    __shared__ uint32_t rowmask[FT_H][2];
+    __shared__ int nA, nB;
+    const uint8_t* px = reinterpret_cast<const uint8_t*>(px4);
+    const int f = blockIdx.y, tid = threadIdx.x;
+    int l = 0;
+    for (int i = 1; i < g->nlevels; i++)
+        if ((int)blockIdx.x >= g->lv[i].tile0) l = i;
+    const LevelGeom L = g->lv[l];
+    const int local = blockIdx.x - L.tile0;
+    const int tix = local % L.tiles_x, tiy = local / L.tiles_x;
+    const int tx0 = tix * FT_W, ty0 = tiy * FT_H;
+    const int w = L.w, h = L.h, pitch = L.pitch;
+    const uint8_t* img = level_px(pyr, g, f, l);
+
+    // phase 0
+    for (int i = tid; i < PX_H * (PX_W / 4); i += 256) {
+        const int r = i / (PX_W / 4), c4 = i - r * (PX_W / 4);
+        const int gy = min(max(ty0 - 4 + r, -VO_PADY), h + VO_PADY - 1);
+        const int gx = min(max(tx0 - 4 + 4 * c4, -VO_PADX), pitch - VO_PADX - 4);
+        px4[i] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
+    }
+    for (int i = tid; i < SM_H * (SM_W + 2); i += 256) (&sm[0][0])[i] = 0;
+    if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
+    if (tid == 0) {
+        nA = 0;
+        nB = 0;
     }
     __syncthreads();
 
-    const int lx = threadIdx.x & 63;
-    const int x = tx0 + lx;
-    uint8_t* out = score + (size_t)f * g->pyr_bytes + g->lv[l].offset;
-    const int opitch = g->lv[l].pitch;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ly = (threadIdx.x >> 6) * 4 + k;
-        const int y = ty0 + ly;
-        if (x >= w || y >= h) continue;
-        int res = 0;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-            const uint8_t* c = &tile[ly + 3][lx + 3];
-            const int v = c[0];
-            int ring[16];
-            ring[0] = c[3 * (FT_W + 8) + 0];
-            ring[1] = c[3 * (FT_W + 8) + 1];
-            ring[2] = c[2 * (FT_W + 8) + 2];
-            ring[3] = c[1 * (FT_W + 8) + 3];
-            ring[4] = c[3];
-            ring[5] = c[-1 * (FT_W + 8) + 3];
-            ring[6] = c[-2 * (FT_W + 8) + 2];
-            ring[7] = c[-3 * (FT_W + 8) + 1];
-            ring[8] = c[-3 * (FT_W + 8) + 0];
-            ring[9] = c[-3 * (FT_W + 8) - 1];
-            ring[10] = c[-2 * (FT_W + 8) - 2];
-            ring[11] = c[-1 * (FT_W + 8) - 3];
-            ring[12] = c[-3];
-            ring[13] = c[1 * (FT_W + 8) - 3];
-            ring[14] = c[2 * (FT_W + 8) - 2];
-            ring[15] = c[3 * (FT_W + 8) - 1];
-            uint32_t dark = 0, bright = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                dark |= (uint32_t)(ring[i] < v - threshold) << i;
-                bright |= (uint32_t)(ring[i] > v + threshold) << i;
-            }
-            // >= 9 contiguous set bits on the 16-ring
-            uint32_t xd = dark | (dark << 16), xb = bright | (bright << 16);
-            uint32_t rd = xd & (xd >> 1), rb = xb & (xb >> 1);
-            rd &= rd >> 2; rb &= rb >> 2;
-            rd &= rd >> 4; rb &= rb >> 4;
-            rd &= xd >> 8; rb &= xb >> 8;
-            if (rd | rb) {
-                // cornerScore<16>: max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1
-                int d[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) d[i] = v - ring[i];
-                int best = threshold;
-                {
-                    int m2[16], m4[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) m2[i] = min(d[i], d[(i + 1) & 15]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 2) & 15]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        int m8 = min(m4[i], m4[(i + 4) & 15]);
-                        best = max(best, min(m8, d[(i + 8) & 15]));
-                    }
-                }
-                {
-                    int m2[16], m4[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) m2[i] = max(d[i], d[(i + 1) & 15]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) m4[i] = max(m2[i], m2[(i + 2) & 15]);
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        int m8 = max(m4[i], m4[(i + 4) & 15]);
-                        best = max(best, -max(m8, d[(i + 8) & 15]));
-                    }
-                }
-                res = best - 1 + 1;
+    // phase A: compass test
+    for (int p0 = 0; p0 < SM_W * SM_H; p0 += 256) {
+        const int p = p0 + tid;
+        bool surv = false;
+        if (p < SM_W * SM_H) {
+            const int sy = p / SM_W, sx = p - sy * SM_W;
+            const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
+            if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+                const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+                const int v = c[0], lo = v - threshold, hi = v + threshold;
+                const int r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
+                const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
+                const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
+                surv = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) ||
+                       (b8 && b12) || (b12 && b0);
             }
         }
-        out[(size_t)y * opitch + x] = (uint8_t)res;
+        const unsigned long long m = __ballot(surv);
+        if (m) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&nA, __popcll(m));
+            base = __shfl(base, 0);
+            if (surv) listA[base + __popcll(m & lanemask_lt())] = (uint16_t)p;
+        }
+    }
+    __syncthreads();
+
+    // phase B: full arc test on the survivors
+    const int na = nA;
+    for (int i0 = 0; i0 < na; i0 += 256) {
+        const int i = i0 + tid;
+        bool corner = false;
+        int p = 0;
+        if (i < na) {
+            p = listA[i];
+            const int sy = p / SM_W, sx = p - sy * SM_W;
+            const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+            const int v = c[0], lo = v - threshold, hi = v + threshold;
+            uint32_t dark = 0, bright = 0;
+#define VO_RING(k, dx, dy)                                                      \
+    {                                                                           \
+        const int r = c[(dy) * PX_W + (dx)];                                    \
+        dark |= (uint32_t)(r < lo) << (k);                                      \
+        bright |= (uint32_t)(r > hi) << (k);                                    \
+    }
+            VO_RING(0, 0, 3) VO_RING(1, 1, 3) VO_RING(2, 2, 2) VO_RING(3, 3, 1)
+            VO_RING(4, 3, 0) VO_RING(5, 3, -1) VO_RING(6, 2, -2) VO_RING(7, 1, -3)
+            VO_RING(8, 0, -3) VO_RING(9, -1, -3) VO_RING(10, -2, -2) VO_RING(11, -3, -1)
+            VO_RING(12, -3, 0) VO_RING(13, -3, 1) VO_RING(14, -2, 2) VO_RING(15, -1, 3)
+#undef VO_RING
+            // >= 9 contiguous set bits on the 16-ring
+            const uint32_t xd = dark | (dark << 16), xb = bright | (bright << 16);
+            uint32_t rd = xd & (xd >> 1), rb = xb & (xb >> 1);
+            rd &= rd >> 2;
+            rb &= rb >> 2;
+            rd &= rd >> 4;
+            rb &= rb >> 4;
+            rd &= xd >> 8;
+            rb &= xb >> 8;
+            corner = ((rd | rb) & 0xffffu) != 0;
+        }
+        const unsigned long long m = __ballot(corner);
+        if (m) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&nB, __popcll(m));
+            base = __shfl(base, 0);
+            if (corner) listB[base + __popcll(m & lanemask_lt())] = (uint16_t)p;
+        }
+    }
+    __syncthreads();
+
+    // phase C: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1
+    const int nb = nB;
+    for (int i = tid; i < nb; i += 256) {
+        const int p = listB[i];
+        const int sy = p / SM_W, sx = p - sy * SM_W;
+        const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+        const int v = c[0];
+        int d[16];
+        d[0] = v - c[3 * PX_W + 0];
+        d[1] = v - c[3 * PX_W + 1];
+        d[2] = v - c[2 * PX_W + 2];
+        d[3] = v - c[1 * PX_W + 3];
+        d[4] = v - c[3];
+        d[5] = v - c[-1 * PX_W + 3];
+        d[6] = v - c[-2 * PX_W + 2];
+        d[7] = v - c[-3 * PX_W + 1];
+        d[8] = v - c[-3 * PX_W + 0];
+        d[9] = v - c[-3 * PX_W - 1];
+        d[10] = v - c[-2 * PX_W - 2];
+        d[11] = v - c[-1 * PX_W - 3];
+        d[12] = v - c[-3];
+        d[13] = v - c[1 * PX_W - 3];
+        d[14] = v - c[2 * PX_W - 2];
+        d[15] = v - c[3 * PX_W - 1];
+        int best = threshold;
+        {
+            int m2[16], m4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int m8 = min(m4[k], m4[(k + 4) & 15]);
+                best = max(best, min(m8, d[(k + 8) & 15]));
+            }
+        }
+        {
+            int m2[16], m4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m2[k] = max(d[k], d[(k + 1) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) m4[k] = max(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int m8 = max(m4[k], m4[(k + 4) & 15]);
+                best = max(best, -max(m8, d[(k + 8) & 15]));
+            }
+        }
+        sm[sy][sx] = (uint8_t)best;  // (best - 1) + 1
+    }
+    __syncthreads();
+
+    // phase D: NMS + border filter on the corners inside the tile
+    const int b = max(border, 3);
+    const bool level_ok = border == 0 || (w > 2 * border && h > 2 * border);
+    uint8_t* sc = level_px(score, g, f, l);
+    for (int i = tid; i < nb; i += 256) {
+        const int p = listB[i];
+        const int sy = p / SM_W, sx = p - sy * SM_W;
+        if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;
+        const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
+        if (!level_ok || x < b || x >= w - b || y < b || y >= h - b) continue;
+        const int s1 = sm[sy][sx];
+        bool kp = true;
+        if (nms) {
+            // the map holds score + 1 (0 = not a corner); cv compares the score with the
+            // neighbours' scores, a neighbour that is not a corner counting as 0
+            const int s = s1 - 1;
+            auto nb8 = [&](int dy, int dx) {
+                const int q = sm[sy + dy][sx + dx];
+                return q ? q - 1 : 0;
+            };
+            kp = s > nb8(0, -1) && s > nb8(0, 1) && s > nb8(-1, -1) && s > nb8(-1, 0) && s > nb8(-1, 1) &&
+                 s > nb8(1, -1) && s > nb8(1, 0) && s > nb8(1, 1);
+        }
+        if (kp) {
+            atomicOr(&rowmask[sy - 1][(sx - 1) >> 5], 1u << ((sx - 1) & 31));
+            sc[(size_t)y * pitch + x] = (uint8_t)s1;
+        }
+    }
+    __syncthreads();
+
+    // phase E
+    if (tid < FT_H) {
+        const int y = ty0 + tid;
+        if (y < h)
+            masks[(size_t)f * g->segs_total + L.seg0 + (size_t)y * L.segs + tix] =
+                (unsigned long long)rowmask[tid][0] | ((unsigned long long)rowmask[tid][1] << 32);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 strict-greater NMS + border filter on the score map; one wave per image row.
-// WRITE=false: per-row keypoint counts.  WRITE=true: ordered (x ascending) compaction into the
-// frame's candidate list at rowofs[row], with the Harris response (7x7 block, k=0.04f) when
-// `harris` is set.  Row-major order is what cv's FAST emits.
+// Per frame: keypoints per row from the masks, exclusive scan over all rows of all levels ->
+// segbase[seg] = position of the first keypoint of that 64-pixel segment in the frame's
+// row-major candidate list; lvlofs[l] = first candidate of level l.  One block per frame.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g,
+                                                   const unsigned long long* __restrict__ masks,
+                                                   int* __restrict__ segbase, int* __restrict__ lvlofs) {
+    __shared__ int part[1024];
+    __shared__ int lvl[VO_ORB_MAX_LEVELS + 1];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int rows = g->rows_total;
+    const int per = (rows + 1023) / 1024;
+    const unsigned long long* M = masks + (size_t)f * g->segs_total;
+    int* SB = segbase + (size_t)f * g->segs_total;
+    int sum = 0;
+    for (int i = 0; i < per; i++) {
+        const int r = t * per + i;
+        if (r < rows) {
+            int l = 0;
+            for (int k = 1; k < g->nlevels; k++)
+                if (r >= g->lv[k].row0) l = k;
+            const int s0 = g->lv[l].seg0 + (r - g->lv[l].row0) * g->lv[l].segs;
+            for (int s = 0; s < g->lv[l].segs; s++) sum += __popcll(M[s0 + s]);
+        }
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = 0; i < per; i++) {
+        const int r = t * per + i;
+        if (r < rows) {
+            int l = 0;
+            for (int k = 1; k < g->nlevels; k++)
+                if (r >= g->lv[k].row0) l = k;
+            if (r == g->lv[l].row0) lvl[l] = run;
+            const int s0 = g->lv[l].seg0 + (r - g->lv[l].row0) * g->lv[l].segs;
+            for (int s = 0; s < g->lv[l].segs; s++) {
+                SB[s0 + s] = run;
+                run += __popcll(M[s0 + s]);
+            }
+        }
+    }
+    if (t == 1023) lvl[g->nlevels] = part[1023];
+    __syncthreads();
+    if (t <= g->nlevels) lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + t] = lvl[t];
+}
+
+// One thread per 64-pixel segment: its keypoints go to the candidate list in x order.
+__global__ __launch_bounds__(256) void k_cand_write(const PyrGeom* __restrict__ g,
+                                                    const unsigned long long* __restrict__ masks,
+                                                    const int* __restrict__ segbase,
+                                                    const uint8_t* __restrict__ score, int nms,
+                                                    Cand* __restrict__ cand, int max_cand) {
+    const int f = blockIdx.y;
+    const int sg = blockIdx.x * 256 + threadIdx.x;
+    if (sg >= g->segs_total) return;
+    unsigned long long m = masks[(size_t)f * g->segs_total + sg];
+    if (!m) return;
+    int l = 0;
+    for (int k = 1; k < g->nlevels; k++)
+        if (sg >= g->lv[k].seg0) l = k;
+    const int local = sg - g->lv[l].seg0;
+    const int y = local / g->lv[l].segs, sx = local - y * g->lv[l].segs;
+    const uint8_t* sc = level_px(score, g, f, l) + (size_t)y * g->lv[l].pitch;
+    int pos = segbase[(size_t)f * g->segs_total + sg];
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int x = sx * 64 + bit;
+        if (pos < max_cand) {
+            Cand cd;
+            cd.x = (int16_t)x;
+            cd.y = (int16_t)y;
+            cd.level = (int16_t)l;
+            cd.score = (int16_t)(nms ? (int)sc[x] - 1 : 0);
+            cd.harris = 0.f;
+            cd.pad = 0;
+            cand[(size_t)f * max_cand + pos] = cd;
+        }
+        pos++;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Harris response (7x7 block, k = 0.04f) in cv's float evaluation order.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
     const int blockSize = 7, r = 3;
     const float harris_k = 0.04f;
     const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
-    const uint8_t* p00 = img + (size_t)(y0 - r) * pitch + (x0 - r);
+    const uint8_t* p00 = img + (ptrdiff_t)(y0 - r) * pitch + (x0 - r);
     int a = 0, b = 0, c = 0;
     for (int i = 0; i < blockSize; i++)
         for (int j = 0; j < blockSize; j++) {
@@ -200,72 +415,8 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
     return (fa * fb - fc * fc - harris_k * (fa + fb) * (fa + fb)) * scale_sq_sq;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_nms_rows(FrameSrc src, const PyrGeom* __restrict__ g,
-                                                 const uint8_t* __restrict__ score, int border, int nms,
-                                                 int harris, int* __restrict__ rowcnt,
-                                                 const int* __restrict__ rowofs, Cand* __restrict__ cand,
-                                                 int max_cand) {
-    const int f = blockIdx.y, row = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int l = find_level_by_row(g, row);
-    const int w = g->lv[l].w, h = g->lv[l].h, pitch = g->lv[l].pitch;
-    const int y = row - g->lv[l].row0;
-    const int b = max(border, 3);
-    int total = 0;
-    const bool level_ok = border == 0 || (w > 2 * border && h > 2 * border);
-    if (level_ok && y >= b && y < h - b) {
-        const uint8_t* S = score + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)y * pitch;
-        int ipitch = 0;
-        const uint8_t* img = nullptr;
-        int base = 0;
-        if (WRITE) {
-            img = level_base(src, g, f, l, ipitch);
-            base = rowofs[(size_t)f * (g->rows_total + 1) + row];
-        }
-        for (int x0 = 0; x0 < w; x0 += 64) {
-            const int x = x0 + lane;
-            bool kp = false;
-            int s = 0;
-            if (x >= b && x < w - b) {
-                const int c = S[x];
-                if (c) {
-                    s = c - 1;
-                    if (nms) {
-                        auto sc = [&](int dy, int dx) {
-                            int v = S[dy * pitch + x + dx];
-                            return v ? v - 1 : 0;
-                        };
-                        kp = s > sc(0, -1) && s > sc(0, 1) && s > sc(-1, -1) && s > sc(-1, 0) &&
-                             s > sc(-1, 1) && s > sc(1, -1) && s > sc(1, 0) && s > sc(1, 1);
-                    } else {
-                        kp = true;
-                        s = 0;
-                    }
-                }
-            }
-            const unsigned long long m = __ballot(kp);
-            if (WRITE && kp) {
-                const int pos = base + total + __popcll(m & ((1ull << lane) - 1ull));
-                if (pos < max_cand) {
-                    Cand cd;
-                    cd.x = (int16_t)x;
-                    cd.y = (int16_t)y;
-                    cd.level = (int16_t)l;
-                    cd.score = (int16_t)s;
-                    cd.harris = 0.f;  // filled by k_harris (one thread per candidate)
-                    cd.pad = 0;
-                    cand[(size_t)f * max_cand + pos] = cd;
-                }
-            }
-            total += __popcll(m);
-        }
-    }
-    if (!WRITE && lane == 0) rowcnt[(size_t)f * g->rows_total + row] = total;
-}
-
-// Harris response of every candidate (ORB): one thread per candidate, dense over the list.
-__global__ __launch_bounds__(256) void k_harris(FrameSrc src, const PyrGeom* __restrict__ g,
+// Harris response of every candidate: only the host selection path needs all of them.
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                 const int* __restrict__ lvlofs, Cand* __restrict__ cand,
                                                 int max_cand) {
     const int f = blockIdx.y;
@@ -273,55 +424,242 @@ __global__ __launch_bounds__(256) void k_harris(FrameSrc src, const PyrGeom* __r
     const int total = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + g->nlevels], max_cand);
     if (i >= total) return;
     Cand* c = cand + (size_t)f * max_cand + i;
-    int pitch;
-    const uint8_t* img = level_base(src, g, f, c->level, pitch);
-    c->harris = harris_response(img, pitch, c->x, c->y);
+    c->harris = harris_response(level_px(pyr, g, f, c->level), g->lv[c->level].pitch, c->x, c->y);
 }
 
-// Exclusive scan of the per-row counts of one frame (one block per frame) -> rowofs[rows+1],
-// plus the per-level start offsets lvlofs[nlevels+1].
-__global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g,
-                                                   const int* __restrict__ rowcnt,
-                                                   int* __restrict__ rowofs, int* __restrict__ lvlofs) {
-    __shared__ int part[1024];
-    const int f = blockIdx.x, t = threadIdx.x;
-    const int rows = g->rows_total;
-    const int per = (rows + 1023) / 1024;
-    const int* cnt = rowcnt + (size_t)f * rows;
-    int* ofs = rowofs + (size_t)f * (rows + 1);
-    int sum = 0;
-    for (int i = 0; i < per; i++) {
-        int r = t * per + i;
-        if (r < rows) sum += cnt[r];
+// ---------------------------------------------------------------------------------------------
+// Device-side keypoint selection: per (frame, level)
+//     retainBest(2 * quota) on the FAST score, Harris response, retainBest(quota) on it,
+// where retainBest = std::nth_element + std::partition of libstdc++ (cv's KeyPointsFilter), whose
+// output PERMUTATION defines the keypoint order and with it every match index downstream.
+// The permutation is reproduced exactly: introselect's median-of-three + unguarded Hoare
+// partition rounds, the final insertion sort, and the bidirectional std::partition.  One Hoare
+// round is data-parallel: the j-th stop of the left pointer is the j-th element that is not
+// "before" the pivot, the j-th stop of the right pointer the j-th from the right that is not
+// "after" it, and the pointers swap exactly while left stop < right stop — so one wavefront finds
+// both stop lists with ballots, counts the swaps and performs them at once.
+// One block per (frame, level): wave 0 runs the selection on the list held in LDS, all waves
+// compute the Harris responses in between.  The depth-limit (heap-select) branch of introselect and
+// lists larger than the LDS buffer are flagged and redone by the host path.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RI {
+    float r;
+    int idx;
+};
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// MODE 0: std::__unguarded_partition(first, last, pivot) with comp(a, b) = a.r > b.r; returns cut.
+// MODE 1: std::__partition(first, last, pred) with pred(a) = a.r >= key; returns the new end.
+template <int MODE>
+__device__ int wave_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int lane) {
+    int nL = 0, nR = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int i0 = first; i0 < last; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < last;
+        const float r = in ? v[i].r : 0.f;
+        bool isL, isR;
+        if (MODE == 0) {
+            isL = in && !(r > key);   // the left pointer stops: !comp(*first, pivot)
+            isR = in && !(key > r);   // the right pointer stops: !comp(pivot, *last)
+        } else {
+            isR = in && (r >= key);   // the right pointer stops on pred
+            isL = in && !(r >= key);  // the left pointer stops on !pred
+        }
+        const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+        if (isL) Lp[nL + __popcll(bL & lt)] = (uint16_t)i;
+        if (isR) Ra[nR + __popcll(bR & lt)] = (uint16_t)i;
+        nL += __popcll(bL);
+        nR += __popcll(bR);
     }
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    lds_fence();
+    const int m = min(nL, nR);
+    int K = 0;  // number of swaps: stops cross monotonically
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        const int k = k0 + lane;
+        const bool ok = k < m && Lp[k] < Ra[nR - 1 - k];
+        K += __popcll(__ballot(ok));
     }
-    int run = part[t] - sum;
-    for (int i = 0; i < per; i++) {
-        int r = t * per + i;
-        if (r < rows) {
-            ofs[r] = run;
-            run += cnt[r];
+    int ret;
+    if (MODE == 0) {
+        const int a = K < nL ? (int)Lp[K] : last;
+        const int b = K > 0 ? (int)Ra[nR - K] : last;
+        ret = min(a, b);
+    } else {
+        ret = first + nR;
+    }
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < K) {
+            const int a = Lp[k], b = Ra[nR - 1 - k];
+            const RI t = v[a];
+            v[a] = v[b];
+            v[b] = t;
         }
     }
-    if (t == 1023) ofs[rows] = part[1023];
-    __syncthreads();
-    __threadfence_block();
-    if (t <= g->nlevels) {
-        const int r = t < g->nlevels ? g->lv[t].row0 : rows;
-        lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + t] = ofs[r];
+    lds_fence();
+    return ret;
+}
+
+// std::nth_element(v + first, v + nth, v + last, greater-by-response); false when libstdc++ would
+// enter its heap-select fallback (depth limit reached).
+__device__ bool wave_nth_element(RI* v, int first, int nth, int last, uint16_t* Lp, uint16_t* Ra, int lane) {
+    if (first == last || nth == last) return true;
+    int depth = 2 * (31 - __clz(last - first));
+    while (last - first > 3) {
+        if (depth == 0) return false;
+        depth--;
+        const int mid = first + (last - first) / 2;
+        const float ra = v[first + 1].r, rb = v[mid].r, rc = v[last - 1].r;
+        int sel;
+        if (ra > rb) {
+            if (rb > rc) sel = mid;
+            else if (ra > rc) sel = last - 1;
+            else sel = first + 1;
+        } else if (ra > rc) sel = first + 1;
+        else if (rb > rc) sel = last - 1;
+        else sel = mid;
+        lds_fence();
+        if (lane == 0) {
+            const RI t = v[first];
+            v[first] = v[sel];
+            v[sel] = t;
+        }
+        lds_fence();
+        const float pivot = v[first].r;
+        const int cut = wave_partition<0>(v, first + 1, last, pivot, Lp, Ra, lane);
+        if (cut <= nth) first = cut;
+        else last = cut;
     }
+    // std::__insertion_sort on the remaining <= 3 elements
+    if (lane == 0) {
+        for (int i = first + 1; i < last; i++) {
+            const RI val = v[i];
+            if (val.r > v[first].r) {
+                for (int j = i; j > first; j--) v[j] = v[j - 1];
+                v[first] = val;
+            } else {
+                int j = i;
+                while (val.r > v[j - 1].r) {
+                    v[j] = v[j - 1];
+                    j--;
+                }
+                v[j] = val;
+            }
+        }
+    }
+    lds_fence();
+    return true;
+}
+
+// KeyPointsFilter::retainBest; returns the new size, -1 on the depth-limit fallback
+__device__ int wave_retain_best(RI* v, int n, int n_points, uint16_t* Lp, uint16_t* Ra, int lane) {
+    if (n_points < 0 || n <= n_points) return n;
+    if (n_points == 0) return 0;
+    if (!wave_nth_element(v, 0, n_points, n, Lp, Ra, lane)) return -1;
+    const float ambiguous = v[n_points - 1].r;
+    return wave_partition<1>(v, n_points, n, ambiguous, Lp, Ra, lane);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
+                                                    const int* __restrict__ lvlofs, Cand* __restrict__ cand,
+                                                    int max_cand, Quotas quota, int sel_cap,
+                                                    int* __restrict__ selidx, int* __restrict__ selcnt,
+                                                    int* __restrict__ flags) {
+    extern __shared__ unsigned char sel_smem[];
+    __shared__ int s_n;
+    RI* v = reinterpret_cast<RI*>(sel_smem);
+    uint16_t* Lp = reinterpret_cast<uint16_t*>(v + sel_cap);
+    uint16_t* Ra = Lp + sel_cap;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;
+    const int b = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l], max_cand);
+    const int e = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l + 1], max_cand);
+    int n = e - b;
+    int* cnt = selcnt + (size_t)f * VO_ORB_MAX_LEVELS + l;
+    if (n > sel_cap) {
+        if (tid == 0) {
+            atomicOr(&flags[f], VO_SEL_OVERSIZE);
+            *cnt = 0;
+        }
+        return;
+    }
+    Cand* C = cand + (size_t)f * max_cand;
+    for (int i = tid; i < n; i += 256) {
+        RI t;
+        t.r = (float)C[b + i].score;
+        t.idx = b + i;
+        v[i] = t;
+    }
+    __syncthreads();
+    if (w0) {
+        const int r = wave_retain_best(v, n, 2 * quota.q[l], Lp, Ra, lane);
+        if (lane == 0) s_n = r;
+    }
+    __syncthreads();
+    n = s_n;
+    if (n < 0) {
+        if (tid == 0) {
+            atomicOr(&flags[f], VO_SEL_DEPTH);
+            *cnt = 0;
+        }
+        return;
+    }
+    const uint8_t* img = level_px(pyr, g, f, l);
+    const int pitch = g->lv[l].pitch;
+    for (int i = tid; i < n; i += 256) {
+        Cand* c = C + v[i].idx;
+        const float hr = harris_response(img, pitch, c->x, c->y);
+        c->harris = hr;
+        v[i].r = hr;
+    }
+    __syncthreads();
+    if (w0) {
+        const int r = wave_retain_best(v, n, quota.q[l], Lp, Ra, lane);
+        if (lane == 0) s_n = r;
+    }
+    __syncthreads();
+    n = s_n;
+    if (n < 0) {
+        if (tid == 0) {
+            atomicOr(&flags[f], VO_SEL_DEPTH);
+            *cnt = 0;
+        }
+        return;
+    }
+    for (int i = tid; i < n; i += 256) selidx[(size_t)f * max_cand + b + i] = v[i].idx;
+    if (tid == 0) *cnt = n;
+}
+
+// keypoints per frame = sum of the per-level selections, checked against the launch bound
+__global__ void k_sel_count(const PyrGeom* __restrict__ g, const int* __restrict__ selcnt, int* __restrict__ flags,
+                            int* __restrict__ nkp, int n_bound, int nframes) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f > nframes) return;
+    if (f == nframes) {
+        nkp[f] = 0;
+        return;
+    }
+    int n = 0;
+    for (int l = 0; l < g->nlevels; l++) n += selcnt[(size_t)f * VO_ORB_MAX_LEVELS + l];
+    if (n > n_bound) {
+        atomicOr(&flags[f], VO_SEL_OVERFLOW);
+        n = n_bound;
+    }
+    nkp[f] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
 // IC angle: integer moments over the radius-15 disc (umax rows), fastAtan2, then the keypoint
-// is written in level-0 coordinates (pt *= scale).  One wave per keypoint.
+// is written in level-0 coordinates (pt *= scale).  One wave per keypoint, two disc rows per step.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float atan2_p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -345,23 +683,45 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_ic_angle(FrameSrc src, const PyrGeom* __restrict__ g,
-                                                  const Cand* __restrict__ sel, const int* __restrict__ nkp,
-                                                  int kp_cap, vo_keypoint* __restrict__ out) {
-    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+__global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
+                                                  const Cand* __restrict__ sel, const Cand* __restrict__ cand,
+                                                  int max_cand, const int* __restrict__ selidx,
+                                                  const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
+                                                  const int* __restrict__ nkp, int kp_cap,
+                                                  vo_keypoint* __restrict__ out) {
+    __shared__ int8_t s_umax[16];
+    if (threadIdx.x < 16) {
+        const int8_t um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+        s_umax[threadIdx.x] = um[threadIdx.x];
+    }
+    __syncthreads();
     const int f = blockIdx.y;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (k >= nkp[f]) return;
-    const Cand cd = sel[(size_t)f * kp_cap + k];
-    int pitch;
-    const uint8_t* img = level_base(src, g, f, cd.level, pitch);
-    const uint8_t* center = img + (size_t)cd.y * pitch + cd.x;
+    Cand cd;
+    if (sel) {
+        cd = sel[(size_t)f * kp_cap + k];
+    } else {
+        int l = 0, rem = k;
+        for (; l < g->nlevels; l++) {
+            const int c = selcnt[(size_t)f * VO_ORB_MAX_LEVELS + l];
+            if (rem < c) break;
+            rem -= c;
+        }
+        const int idx = selidx[(size_t)f * max_cand + lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l] + rem];
+        cd = cand[(size_t)f * max_cand + idx];
+    }
+    const int pitch = g->lv[cd.level].pitch;
+    const uint8_t* center = level_px(pyr, g, f, cd.level) + (ptrdiff_t)cd.y * pitch + cd.x;
     int m01 = 0, m10 = 0;
-    for (int idx = lane; idx < 31 * 31; idx += 64) {
-        const int v = idx / 31 - 15, u = idx % 31 - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= umax[av]) {
+    const int u = (lane & 31) - 15;
+    const int au = u < 0 ? -u : u;
+#pragma unroll 4
+    for (int step = 0; step < 16; step++) {
+        const int v = -15 + 2 * step + (lane >> 5);
+        const int av = v < 0 ? -v : v;
+        if (v <= 15 && au <= 15 && au <= s_umax[av & 15]) {
             const int val = center[v * pitch + u];
             m10 += u * val;
             m01 += v * val;
@@ -387,48 +747,63 @@ __global__ __launch_bounds__(256) void k_ic_angle(FrameSrc src, const PyrGeom* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// GaussianBlur 7x7 sigma 2 (cv's 8-bit fixed-point separable path, BORDER_REFLECT_101):
-// row pass in 32-bit ints (fits 16), column pass (sum + 2^15) >> 16, saturate.
+// GaussianBlur 7x7 sigma 2 (cv's 8-bit fixed-point separable path, BORDER_REFLECT_101): row pass
+// in 32-bit ints, column pass (sum + 2^15) >> 16, saturate.  No LDS: a thread owns a column of four
+// pixels, reads three aligned dwords per input row (the reflect-101 frame is real memory) and
+// keeps the last seven row sums in registers while it walks down GB_ROWS output rows.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gauss7(FrameSrc src, const PyrGeom* __restrict__ g,
-                                                uint8_t* __restrict__ blur, Taps7 taps, int nlevels_used) {
-    __shared__ uint8_t raw[FT_H + 6][FT_W + 8];
-    __shared__ uint16_t hz[FT_H + 6][FT_W];
-    const int f = blockIdx.y;
-    int local;
-    const int l = find_level_by_tile(g, blockIdx.x, local);
-    if (l >= nlevels_used) return;
-    const int w = g->lv[l].w, h = g->lv[l].h;
-    const int tiles_x = (w + FT_W - 1) / FT_W;
-    const int tx0 = (local % tiles_x) * FT_W, ty0 = (local / tiles_x) * FT_H;
-    int pitch;
-    const uint8_t* img = level_base(src, g, f, l, pitch);
-    for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-        const int r = i / (FT_W + 6), c = i - r * (FT_W + 6);
-        const int gx = reflect101(tx0 + c - 3, w), gy = reflect101(ty0 + r - 3, h);
-        raw[r][c] = img[(size_t)gy * pitch + gx];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (FT_H + 6) * FT_W; i += 256) {
-        const int r = i / FT_W, c = i - r * FT_W;
-        int acc = 0;
+#define GB_ROWS 16
+__global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
+                                                uint8_t* __restrict__ blur, Taps7 taps, int level) {
+    const int f = blockIdx.z;
+    const int w = g->lv[level].w, h = g->lv[level].h, pitch = g->lv[level].pitch;
+    const int x4 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y0 = GB_ROWS * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (x4 >= w || y0 >= h) return;
+    const uint8_t* src = level_px(pyr, g, f, level) + x4;
+    uint8_t* dst = level_px(blur, g, f, level) + x4;
+    // all quantities are non-negative and below 2^24: 24-bit multiplies (full rate), unsigned math
+    uint32_t t[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) acc += taps.t[k] * raw[r][c + k];
-        hz[r][c] = (uint16_t)acc;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63, x = tx0 + lx;
-    uint8_t* out = blur + (size_t)f * g->pyr_bytes + g->lv[l].offset;
-    const int opitch = g->lv[l].pitch;
+    for (int k = 0; k < 7; k++) t[k] = (uint32_t)taps.t[k];
+    uint32_t H[7][4] = {};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ly = (threadIdx.x >> 6) * 4 + k, y = ty0 + ly;
-        if (x >= w || y >= h) continue;
-        int acc = 0;
+    for (int r = 0; r < GB_ROWS + 6; r++) {
+        const int y = min(y0 - 3 + r, h + 2);
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(src + (ptrdiff_t)y * pitch);
+        const uint32_t A = row[-1], B = row[0], C = row[1];
+        uint32_t b[12];
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += taps.t[j] * (int)hz[ly + j][lx];
-        const int v = (acc + (1 << 15)) >> 16;
-        out[(size_t)y * opitch + x] = (uint8_t)min(max(v, 0), 255);
+        for (int k = 0; k < 4; k++) {
+            b[k] = (A >> (8 * k)) & 0xffu;
+            b[4 + k] = (B >> (8 * k)) & 0xffu;
+            b[8 + k] = (C >> (8 * k)) & 0xffu;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) H[q][j] = H[q + 1][j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) acc += __umul24(t[k], b[1 + j + k]);
+            H[6][j] = acc;
+        }
+        if (r >= 6) {
+            const int yo = y0 + r - 6;
+            if (yo < h) {
+                uint32_t o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t acc = 1u << 15;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) acc += __umul24(t[q], H[q][j]);
+                    o |= min(acc >> 16, 255u) << (8 * j);
+                }
+                *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)yo * pitch) = o;
+            }
+        }
     }
 }
 
@@ -458,7 +833,7 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     angle *= (float)(3.14159265358979323846 / 180.f);
     const float ca = (float)cos((double)angle), sa = (float)sin((double)angle);
     const int cy = __float2int_rn(kp.y * scale), cx = __float2int_rn(kp.x * scale);
-    const uint8_t* center = blur + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)cy * pitch + cx;
+    const uint8_t* center = level_px(blur, g, f, l) + (ptrdiff_t)cy * pitch + cx;
     const int8_t* p = pat + b * 32;
     int val = 0;
 #pragma unroll
@@ -479,56 +854,68 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
-void launch_pyr_resize(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                       uint8_t* pyr, int level, const uint32_t* xtab, const uint32_t* ytab, int nframes) {
-    dim3 grid(cdiv(hg.lv[level].w, 64), cdiv(hg.lv[level].h, 4), nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, src, d_geom, pyr, level, xtab, ytab);
+void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, int stride, const PyrGeom* d_geom,
+                       const PyrGeom& hg, uint8_t* pyr, int nframes) {
+    dim3 grid(cdiv(cdiv(hg.lv[0].w + 7, 4), 64), cdiv(hg.lv[0].h + 6, 4), nframes);
+    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, d_geom, pyr);
 }
 
-void launch_fast_score(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                       uint8_t* score, int threshold, int nframes) {
+void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
+                       const uint32_t* xtab, const uint32_t* ytab, int nframes) {
+    dim3 grid(cdiv(cdiv(hg.lv[level].w + 7, 4), 64), cdiv(hg.lv[level].h + 6, 4), nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_geom, pyr, level, xtab, ytab);
+}
+
+void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
+                     unsigned long long* masks, int threshold, int border, int nms, int nframes) {
     dim3 grid(hg.tiles_total, nframes);
-    hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, st, src, d_geom, score, threshold);
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms);
 }
 
-void launch_nms_count(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                      const uint8_t* score, int border, int nms, int* rowcnt, int nframes) {
-    dim3 grid(hg.rows_total, nframes);
-    hipLaunchKernelGGL(k_nms_rows<false>, grid, dim3(64), 0, st, src, d_geom, score, border, nms, 0,
-                       rowcnt, (const int*)nullptr, (Cand*)nullptr, 0);
+void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
+                     int* lvlofs, int nframes) {
+    hipLaunchKernelGGL(k_row_scan, dim3(nframes), dim3(1024), 0, st, d_geom, masks, segbase, lvlofs);
 }
 
-void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const int* rowcnt, int* rowofs, int* lvlofs,
-                     int nframes) {
-    hipLaunchKernelGGL(k_row_scan, dim3(nframes), dim3(1024), 0, st, d_geom, rowcnt, rowofs, lvlofs);
+void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
+                       const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes) {
+    dim3 grid(cdiv(hg.segs_total, 256), nframes);
+    hipLaunchKernelGGL(k_cand_write, grid, dim3(256), 0, st, d_geom, masks, segbase, score, nms, cand, max_cand);
 }
 
-void launch_nms_write(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                      const uint8_t* score, int border, int nms, int harris, const int* rowofs,
-                      Cand* cand, int max_cand, int nframes) {
-    dim3 grid(hg.rows_total, nframes);
-    hipLaunchKernelGGL(k_nms_rows<true>, grid, dim3(64), 0, st, src, d_geom, score, border, nms, harris,
-                       (int*)nullptr, rowofs, cand, max_cand);
-}
-
-void launch_harris(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
+void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
                    int max_cand, int grid_cand, int nframes) {
     dim3 grid(cdiv(grid_cand, 256), nframes);
-    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, st, src, d_geom, lvlofs, cand, max_cand);
+    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, st, pyr, d_geom, lvlofs, cand, max_cand);
 }
 
-void launch_ic_angle(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const Cand* sel,
-                     const int* nkp, int kp_cap, int max_n, vo_keypoint* out, int nframes) {
+void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
+                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, int* selidx,
+                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes) {
+    const size_t lds = (size_t)sel_cap * (sizeof(RI) + 2 * sizeof(uint16_t));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_select),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_orb_select, dim3(hg.nlevels, nframes), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
+                       max_cand, quota, sel_cap, selidx, selcnt, flags);
+    hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
+                       n_bound, nframes);
+}
+
+void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const Cand* cand,
+                     int max_cand, const int* selidx, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int max_n, vo_keypoint* out, int nframes) {
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, 4), nframes);
-    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, src, d_geom, sel, nkp, kp_cap, out);
+    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, cand, max_cand, selidx, selcnt, lvlofs,
+                       nkp, kp_cap, out);
 }
 
-void launch_gauss7(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                   uint8_t* blur, const Taps7& taps, int nlevels_used, int nframes) {
-    int tiles = nlevels_used >= hg.nlevels ? hg.tiles_total : hg.tile_start[nlevels_used];
-    dim3 grid(tiles, nframes);
-    hipLaunchKernelGGL(k_gauss7, grid, dim3(256), 0, st, src, d_geom, blur, taps, nlevels_used);
+void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
+                   const Taps7& taps, int nlevels_used, int nframes) {
+    for (int l = 0; l < nlevels_used && l < hg.nlevels; l++) {
+        dim3 grid(cdiv(cdiv(hg.lv[l].w, 4), 64), cdiv(cdiv(hg.lv[l].h, GB_ROWS), 4), nframes);
+        hipLaunchKernelGGL(k_gauss7, grid, dim3(256), 0, st, pyr, d_geom, blur, taps, l);
+    }
 }
 
 void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,

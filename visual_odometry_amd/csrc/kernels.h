@@ -12,31 +12,29 @@
 static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- ORB pyramid geometry (one copy on the host, one in device memory) ------------------------
-// Levels live tightly packed per frame: level l at byte `offset`, rows `pitch` bytes apart
-// (pitch = width rounded up to 64).  The same layout is used for the pyramid (levels >= 1; level 0
-// is read from the caller's image), the FAST score map and the blurred pyramid.
+// Every frame owns one packed buffer holding all levels (level 0 is a copy of the caller's image).
+// A level is stored with a border: VO_PADX bytes left of x = 0 and VO_PADY rows above y = 0, so
+// pixel (0,0) sits on a 16-byte boundary, rows are `pitch` (multiple of 64) bytes apart and the
+// 3-pixel reflect-101 frame the 7x7 blur reads is real memory.  The same layout is used for the
+// pyramid, the blurred pyramid and the (sparsely written) FAST score map.
+#define VO_PADX 16
+#define VO_PADY 4
 struct LevelGeom {
     int w, h;
     int pitch;
     int row0;         // first row of this level in the frame-wide row table
-    unsigned offset;  // byte offset inside a frame's packed buffer
+    unsigned offset;  // byte offset of the padded level inside a frame's packed buffer
     float scale;      // cv layerScale
+    int seg0, segs;   // first 64-pixel row segment of this level in the frame-wide mask table, segments per row
+    int tile0, tiles_x;  // first 64x32 detector tile of this level, tiles per tile row
 };
 struct PyrGeom {
     int nlevels;
     int rows_total;      // sum of level heights
     unsigned pyr_bytes;  // packed bytes per frame
-    int tiles_total;     // 64x16 tiles over all levels
-    int tile_start[VO_ORB_MAX_LEVELS + 1];
+    int tiles_total;     // 64x32 tiles over all levels
+    int segs_total;      // 64-pixel row segments over all levels
     LevelGeom lv[VO_ORB_MAX_LEVELS];
-};
-
-// where the unblurred pixels of a frame live
-struct FrameSrc {
-    const uint8_t* img;   // level 0: caller's frames
-    size_t frame_stride;  // bytes between frames in img
-    int stride;           // bytes per row in img
-    const uint8_t* pyr;   // packed pyramid (levels >= 1)
 };
 
 struct Taps7 {
@@ -52,24 +50,37 @@ struct Cand {
     uint32_t pad;
 };
 
+struct Quotas {
+    int q[VO_ORB_MAX_LEVELS];
+};
+
+// flags raised by the device-side keypoint selection (per frame); any flag sends the batch through
+// the host selection path, which is exact for every input
+#define VO_SEL_OVERSIZE 1   // a level has more candidates than the LDS selection buffer holds
+#define VO_SEL_DEPTH 2      // introselect ran out of its depth budget (heap-select fallback in libstdc++)
+#define VO_SEL_OVERFLOW 4   // more keypoints selected than the launch bound of the later stages
+
 // ---- features -----------------------------------------------------------------------------
-void launch_pyr_resize(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                       uint8_t* pyr, int level, const uint32_t* xtab, const uint32_t* ytab, int nframes);
-void launch_fast_score(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                       uint8_t* score, int threshold, int nframes);
-void launch_nms_count(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                      const uint8_t* score, int border, int nms, int* rowcnt, int nframes);
-void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const int* rowcnt, int* rowofs, int* lvlofs,
-                     int nframes);
-void launch_nms_write(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                      const uint8_t* score, int border, int nms, int harris, const int* rowofs,
-                      Cand* cand, int max_cand, int nframes);
-void launch_harris(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
+void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, int stride, const PyrGeom* d_geom,
+                       const PyrGeom& hg, uint8_t* pyr, int nframes);
+void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
+                       const uint32_t* xtab, const uint32_t* ytab, int nframes);
+void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
+                     unsigned long long* masks, int threshold, int border, int nms, int nframes);
+void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
+                     int* lvlofs, int nframes);
+void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
+                       const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes);
+void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
                    int max_cand, int grid_cand, int nframes);
-void launch_ic_angle(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const Cand* sel,
-                     const int* nkp, int kp_cap, int max_n, vo_keypoint* out, int nframes);
-void launch_gauss7(hipStream_t st, const FrameSrc& src, const PyrGeom* d_geom, const PyrGeom& hg,
-                   uint8_t* blur, const Taps7& taps, int nlevels_used, int nframes);
+void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
+                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, int* selidx,
+                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes);
+void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const Cand* cand,
+                     int max_cand, const int* selidx, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int max_n, vo_keypoint* out, int nframes);
+void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
+                   const Taps7& taps, int nlevels_used, int nframes);
 void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,
                    const int* nkp, int kp_cap, int max_n, uint8_t* desc, int nframes);
 

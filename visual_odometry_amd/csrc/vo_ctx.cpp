@@ -100,7 +100,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_rowcnt, &c->d_rowofs,
+    DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_masks, &c->d_segbase, &c->d_selidx, &c->d_selcnt, &c->d_flags,
                      &c->d_lvlofs, &c->d_cand,  &c->d_sel,   &c->d_coef,   &c->d_geom,   &c->d_kp,
                      &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,
                      &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,
@@ -109,7 +109,7 @@ void vo_ctx_destroy(vo_ctx* c) {
                      &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj};
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
-    PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_knn,
+    PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
                         &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
@@ -130,6 +130,24 @@ int vo_ctx_synchronize(vo_ctx* c) {
 int vo_prof_enable(vo_ctx* c, int on) {
     if (!c) return VO_ERR_INVALID;
     c->prof_on = on != 0;
+    return VO_OK;
+}
+
+int vo_ctx_set_option(vo_ctx* c, int option, int value) {
+    if (!c) return VO_ERR_INVALID;
+    if (option == VO_OPT_SEL_CAP) {
+        if (value < 8 || value > 13000) return c->fail(VO_ERR_INVALID, "VO_OPT_SEL_CAP must be in [8, 13000]");
+        c->sel_cap = value;
+        return VO_OK;
+    }
+    return c->fail(VO_ERR_INVALID, "unknown or read-only option %d", option);
+}
+
+int vo_ctx_get_option(vo_ctx* c, int option, int* value) {
+    if (!c || !value) return VO_ERR_INVALID;
+    if (option == VO_OPT_SEL_CAP) *value = c->sel_cap;
+    else if (option == VO_OPT_LAST_FLAGS) *value = c->last_flags;
+    else return c->fail(VO_ERR_INVALID, "unknown option %d", option);
     return VO_OK;
 }
 

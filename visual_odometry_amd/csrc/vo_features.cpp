@@ -1,7 +1,8 @@
 // vo_features.cpp — host side of the FAST / ORB entry points: pyramid geometry (cv's level
 // sizes, quotas and INTER_LINEAR_EXACT coefficient tables), kernel sequencing, and the
-// response-ordered keypoint selection (KeyPointsFilter::retainBest) whose output permutation is
-// defined by libstdc++'s nth_element/partition and therefore runs on the host.
+// response-ordered keypoint selection (KeyPointsFilter::retainBest), whose output permutation is
+// defined by libstdc++'s nth_element/partition: reproduced on the device (k_orb_select), with this
+// file's host implementation (libstdc++ itself) as the path for inputs the device kernel flags.
 // Replaces FeatureDetector's cv calls (reference: src/features/feature_detector.cpp:3-42).
 #include <algorithm>
 #include <cmath>
@@ -108,7 +109,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
         g.nlevels = nlevels;
         const double scaleFactor = (double)sf;
         unsigned off = 0;
-        int row = 0, tile = 0;
+        int row = 0, tile = 0, seg = 0;
         for (int l = 0; l < nlevels; l++) {
             const float s = (float)std::pow(scaleFactor, (double)l);
             LevelGeom& L = g.lv[l];
@@ -116,17 +117,21 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
             L.w = cv_roundf(w / s);
             L.h = cv_roundf(h / s);
             if (L.w < 7 || L.h < 7) return c->fail(VO_ERR_INVALID, "pyramid level %d is too small", l);
-            L.pitch = (L.w + 63) & ~63;
+            L.pitch = (L.w + 2 * VO_PADX + 63) & ~63;
             L.offset = off;
             L.row0 = row;
-            off += (unsigned)L.pitch * L.h;
+            off += (unsigned)L.pitch * (L.h + 2 * VO_PADY);
             off = (off + 255u) & ~255u;
             row += L.h;
-            g.tile_start[l] = tile;
-            tile += cdiv(L.w, 64) * cdiv(L.h, 16);
+            L.segs = cdiv(L.w, 64);
+            L.seg0 = seg;
+            seg += L.segs * L.h;
+            L.tiles_x = L.segs;
+            L.tile0 = tile;
+            tile += L.tiles_x * cdiv(L.h, 32);
         }
-        g.tile_start[nlevels] = tile;
         g.tiles_total = tile;
+        g.segs_total = seg;
         g.rows_total = row;
         g.pyr_bytes = off;
         // coefficient tables for levels >= 1
@@ -176,46 +181,53 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     VO_TRY(vo_ensure(c, c->d_pyr, nf * c->geom.pyr_bytes));
     VO_TRY(vo_ensure(c, c->d_blur, nf * c->geom.pyr_bytes));
     VO_TRY(vo_ensure(c, c->d_score, nf * c->geom.pyr_bytes));
-    VO_TRY(vo_ensure(c, c->d_rowcnt, nf * c->geom.rows_total * sizeof(int)));
-    VO_TRY(vo_ensure(c, c->d_rowofs, nf * (c->geom.rows_total + 1) * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_masks, nf * c->geom.segs_total * sizeof(unsigned long long)));
+    VO_TRY(vo_ensure(c, c->d_segbase, nf * c->geom.segs_total * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
+    VO_TRY(vo_ensure(c, c->d_selidx, nf * c->max_cand * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_selcnt, nf * VO_ORB_MAX_LEVELS * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_flags, (nf + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_sel, nf * kp_cap * sizeof(Cand)));
     VO_TRY(vo_ensure(c, c->d_kp, nf * kp_cap * sizeof(vo_keypoint)));
     VO_TRY(vo_ensure(c, c->d_desc, nf * kp_cap * 32));
     VO_TRY(vo_ensure(c, c->d_nkp, (nf + 1) * sizeof(int)));
     VO_TRY(vo_ensure_pinned(c, c->h_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
-    VO_TRY(vo_ensure_pinned(c, c->h_cand, nf * c->max_cand * sizeof(Cand)));
-    VO_TRY(vo_ensure_pinned(c, c->h_sel, nf * kp_cap * sizeof(Cand)));
     VO_TRY(vo_ensure_pinned(c, c->h_nkp, (nf + 1) * sizeof(int)));
+    VO_TRY(vo_ensure_pinned(c, c->h_flags, (nf + 1) * sizeof(int)));
     c->feat_frames = nframes;
     return VO_OK;
 }
 
-// Stage A: pyramid, FAST score, NMS + border filter + ordered compaction (+ Harris).  On return
-// h_lvlofs[f][0..nlevels] and h_cand[f][0..total) are valid on the host.
-int feat_detect(vo_ctx* c, const FrameSrc& src_in, int nframes, int fast_threshold, int border, int nms,
-                int harris) {
+// Stage A (asynchronous): padded pyramid, fused FAST + NMS + border filter tiles, row-major
+// candidate lists.  d_img: nframes images in device memory.
+int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes, int fast_threshold,
+                int border, int nms) {
     const PyrGeom& g = c->geom;
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
-    FrameSrc src = src_in;
-    src.pyr = c->d_pyr.as<uint8_t>();
     hipStream_t st = c->stream;
+    uint8_t* pyr = c->d_pyr.as<uint8_t>();
+    launch_pyr_level0(st, d_img, frame_stride, stride, dg, g, pyr, nframes);
     for (int l = 1; l < g.nlevels; l++)
-        launch_pyr_resize(st, src, dg, g, c->d_pyr.as<uint8_t>(), l, c->d_coef.as<uint32_t>() + c->coef_x[l],
+        launch_pyr_resize(st, dg, g, pyr, l, c->d_coef.as<uint32_t>() + c->coef_x[l],
                           c->d_coef.as<uint32_t>() + c->coef_y[l], nframes);
     {
         ProfScope ps(c, VO_PROF_FAST);
-        launch_fast_score(st, src, dg, g, c->d_score.as<uint8_t>(), std::min(std::max(fast_threshold, 0), 255),
-                          nframes);
+        launch_fast_nms(st, dg, g, pyr, c->d_score.as<uint8_t>(), c->d_masks.as<unsigned long long>(),
+                        std::min(std::max(fast_threshold, 0), 255), border, nms, nframes);
     }
-    launch_nms_count(st, src, dg, g, c->d_score.as<uint8_t>(), border, nms, c->d_rowcnt.as<int>(), nframes);
-    launch_row_scan(st, dg, c->d_rowcnt.as<int>(), c->d_rowofs.as<int>(), c->d_lvlofs.as<int>(), nframes);
-    launch_nms_write(st, src, dg, g, c->d_score.as<uint8_t>(), border, nms, harris, c->d_rowofs.as<int>(),
-                     c->d_cand.as<Cand>(), c->max_cand, nframes);
-    if (harris)
-        launch_harris(st, src, dg, c->d_lvlofs.as<int>(), c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
-    VO_TRY(vo_check_launch(c, "feature detection"));
+    launch_row_scan(st, dg, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(), c->d_lvlofs.as<int>(),
+                    nframes);
+    launch_cand_write(st, dg, g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
+                      c->d_score.as<uint8_t>(), nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
+    return vo_check_launch(c, "feature detection");
+}
+
+// Candidate lists to the host (plain FAST output, host selection path).  Synchronises.
+int feat_fetch_cands(vo_ctx* c, int nframes) {
+    const PyrGeom& g = c->geom;
+    hipStream_t st = c->stream;
+    VO_TRY(vo_ensure_pinned(c, c->h_cand, (size_t)nframes * c->max_cand * sizeof(Cand)));
     const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
     VO_HIP(c, hipMemcpyAsync(c->h_lvlofs.p, c->d_lvlofs.p, lv_bytes, hipMemcpyDeviceToHost, st));
     VO_HIP(c, hipStreamSynchronize(st));
@@ -234,10 +246,30 @@ int feat_detect(vo_ctx* c, const FrameSrc& src_in, int nframes, int fast_thresho
     return VO_OK;
 }
 
-// ORB keypoint selection per frame and level: retainBest(2*quota) on the FAST score, then
-// retainBest(quota) on the Harris response, in cv's order.  Uploads the selection.
-int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out) {
+// ORB keypoint selection on the device (asynchronous): per frame and level retainBest(2*quota) on
+// the FAST score, Harris, retainBest(quota), in cv's order.  n_bound: keypoints per frame the later
+// launches are sized for.  d_flags[f] != 0 afterwards means frame f needs the host path.
+int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
+    hipStream_t st = c->stream;
+    Quotas q;
+    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) q.q[l] = l < c->geom.nlevels ? c->quota[l] : 0;
+    VO_HIP(c, hipMemsetAsync(c->d_flags.p, 0, (size_t)(nframes + 1) * sizeof(int), st));
+    launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom, c->d_lvlofs.as<int>(),
+                      c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selidx.as<int>(), c->d_selcnt.as<int>(),
+                      c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes);
+    return vo_check_launch(c, "keypoint selection");
+}
+
+// The same selection on the host with libstdc++ itself (exact for every input; used when the
+// device selection raised a flag).  Harris for every candidate, candidates to the host, selection
+// on host threads, upload of the selected keypoints.  Synchronises.
+int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     const PyrGeom& g = c->geom;
+    launch_harris(c->stream, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->d_lvlofs.as<int>(),
+                  c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
+    VO_TRY(vo_check_launch(c, "harris"));
+    VO_TRY(feat_fetch_cands(c, nframes));
+    VO_TRY(vo_ensure_pinned(c, c->h_sel, (size_t)nframes * c->kp_cap * sizeof(Cand)));
     const int* lv = c->h_lvlofs.as<int>();
     int* nkp = c->h_nkp.as<int>();
     // frames are independent: the (sequential, libstdc++-defined) selections run on host threads
@@ -287,30 +319,59 @@ int feat_select_orb(vo_ctx* c, int nframes, int* max_n_out) {
     return VO_OK;
 }
 
-// Stage B: IC angles (optional), blur, rBRIEF for nkp[f] keypoints per frame.
-int feat_describe(vo_ctx* c, const FrameSrc& src_in, int nframes, int max_n, bool angles) {
+// Stage B (asynchronous): IC angles (optional), blur, rBRIEF for d_nkp[f] keypoints per frame;
+// max_n bounds the launches.
+int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_selection) {
     static const Taps7 taps = gauss_taps();
     const PyrGeom& g = c->geom;
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
-    FrameSrc src = src_in;
-    src.pyr = c->d_pyr.as<uint8_t>();
     if (angles)
-        launch_ic_angle(c->stream, src, dg, c->d_sel.as<Cand>(), c->d_nkp.as<int>(), c->kp_cap, max_n,
-                        c->d_kp.as<vo_keypoint>(), nframes);
-    launch_gauss7(c->stream, src, dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
+        launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
+                        c->d_cand.as<Cand>(), c->max_cand, c->d_selidx.as<int>(), c->d_selcnt.as<int>(),
+                        c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
+                        nframes);
+    launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
     launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
                   c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
     return vo_check_launch(c, "feature description");
 }
 
-static int upload_image(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, FrameSrc& src) {
-    const int pitch = (w + 63) & ~63;
-    VO_TRY(vo_ensure(c, c->d_img, (size_t)pitch * h));
-    VO_HIP(c, hipMemcpy2DAsync(c->d_img.p, pitch, gray, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    src.img = c->d_img.as<uint8_t>();
-    src.frame_stride = (size_t)pitch * h;
-    src.stride = pitch;
-    src.pyr = nullptr;
+// Launch bound for the stages after the device selection: nfeatures plus room for response ties.
+int feat_n_bound(const vo_ctx* c, int nfeatures) {
+    return std::min({c->kp_cap, nfeatures + nfeatures / 8 + 64, c->lim.max_points});
+}
+
+// ORB keypoints of nframes device-resident frames into d_kp / d_desc / d_nkp: device selection,
+// host selection when a flag was raised.  Synchronises once; h_nkp holds the counts.
+int feat_orb_frames(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes,
+                    const vo_orb_params* p, int* max_n_out) {
+    VO_TRY(feat_detect(c, d_img, frame_stride, stride, nframes, p->fast_threshold, p->edge_threshold, 1));
+    const int n_bound = feat_n_bound(c, p->nfeatures);
+    VO_TRY(feat_select_dev(c, nframes, n_bound));
+    VO_TRY(feat_describe(c, nframes, n_bound, true, false));
+    VO_HIP(c, hipMemcpyAsync(c->h_flags.p, c->d_flags.p, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost,
+                             c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_nkp.p, c->d_nkp.p, (size_t)(nframes + 1) * sizeof(int), hipMemcpyDeviceToHost,
+                             c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    int flagged = 0, max_n = 0;
+    for (int f = 0; f < nframes; f++) {
+        flagged |= c->h_flags.as<int>()[f];
+        max_n = std::max(max_n, c->h_nkp.as<int>()[f]);
+    }
+    c->last_flags = flagged;
+    if (flagged) {
+        VO_TRY(feat_select_host(c, nframes, &max_n));
+        if (max_n > 0) VO_TRY(feat_describe(c, nframes, max_n, true, true));
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *max_n_out = max_n;
+    return VO_OK;
+}
+
+static int upload_image(vo_ctx* c, const uint8_t* gray, int w, int h, int stride) {
+    VO_TRY(vo_ensure(c, c->d_img, (size_t)w * h));
+    VO_HIP(c, hipMemcpy2DAsync(c->d_img.p, w, gray, stride, w, h, hipMemcpyHostToDevice, c->stream));
     return VO_OK;
 }
 
@@ -325,9 +386,9 @@ int vo_fast_detect(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, int
     *n = 0;
     if (w < 7 || h < 7) return VO_OK;  // cv: no pixel has a full ring
     VO_TRY(feat_setup(c, w, h, nullptr, 1));
-    FrameSrc src;
-    VO_TRY(upload_image(c, gray, w, h, stride, src));
-    VO_TRY(feat_detect(c, src, 1, threshold, 0, nms != 0, 0));
+    VO_TRY(upload_image(c, gray, w, h, stride));
+    VO_TRY(feat_detect(c, c->d_img.as<uint8_t>(), (size_t)w * h, w, 1, threshold, 0, nms != 0));
+    VO_TRY(feat_fetch_cands(c, 1));
     const int total = c->h_lvlofs.as<int>()[1];
     const Cand* cand = c->h_cand.as<Cand>();
     *n = total;
@@ -346,6 +407,23 @@ int vo_fast_detect(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, int
     return VO_OK;
 }
 
+int vo_debug_read_level(vo_ctx* c, int which, int frame, int level, uint8_t* out, int cap, int* w, int* h) {
+    if (!c) return VO_ERR_INVALID;
+    if (!out || !w || !h || frame < 0 || frame >= c->feat_frames || level < 0 || level >= c->geom.nlevels ||
+        (which != VO_DBG_PYRAMID && which != VO_DBG_BLUR))
+        return c->fail(VO_ERR_INVALID, "vo_debug_read_level: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    const LevelGeom& L = c->geom.lv[level];
+    *w = L.w;
+    *h = L.h;
+    if (cap < L.w * L.h) return c->fail(VO_ERR_CAPACITY, "vo_debug_read_level: need %d bytes", L.w * L.h);
+    const uint8_t* base = (which == VO_DBG_PYRAMID ? c->d_pyr.as<uint8_t>() : c->d_blur.as<uint8_t>()) +
+                          (size_t)frame * c->geom.pyr_bytes + L.offset + (size_t)VO_PADY * L.pitch + VO_PADX;
+    VO_HIP(c, hipMemcpy2DAsync(out, L.w, base, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    return VO_OK;
+}
+
 int vo_orb_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, const vo_orb_params* p,
                           vo_keypoint* kp, uint8_t* desc, int cap, int* n) {
     if (!c) return VO_ERR_INVALID;
@@ -357,16 +435,13 @@ int vo_orb_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stri
     VO_HIP(c, hipSetDevice(c->device));
     *n = 0;
     VO_TRY(feat_setup(c, w, h, p, 1));
-    FrameSrc src;
-    VO_TRY(upload_image(c, gray, w, h, stride, src));
-    VO_TRY(feat_detect(c, src, 1, p->fast_threshold, p->edge_threshold, 1, 1));
+    VO_TRY(upload_image(c, gray, w, h, stride));
     int max_n = 0;
-    VO_TRY(feat_select_orb(c, 1, &max_n));
+    VO_TRY(feat_orb_frames(c, c->d_img.as<uint8_t>(), (size_t)w * h, w, 1, p, &max_n));
     const int cnt = c->h_nkp.as<int>()[0];
     *n = cnt;
     if (cnt > cap) return c->fail(VO_ERR_CAPACITY, "vo_orb_detect_compute: %d keypoints, capacity %d", cnt, cap);
     if (cnt == 0) return VO_OK;
-    VO_TRY(feat_describe(c, src, 1, max_n, true));
     if (kp) VO_HIP(c, hipMemcpyAsync(kp, c->d_kp.p, (size_t)cnt * sizeof(vo_keypoint), hipMemcpyDeviceToHost, c->stream));
     if (desc) VO_HIP(c, hipMemcpyAsync(desc, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
@@ -410,11 +485,11 @@ int vo_orb_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, con
     vo_orb_params pp = *p;
     pp.nlevels = nlevels;  // only the levels the keypoints use are built
     VO_TRY(feat_setup(c, w, h, &pp, 1));
-    FrameSrc src;
-    VO_TRY(upload_image(c, gray, w, h, stride, src));
-    src.pyr = c->d_pyr.as<uint8_t>();
+    VO_TRY(upload_image(c, gray, w, h, stride));
+    launch_pyr_level0(c->stream, c->d_img.as<uint8_t>(), (size_t)w * h, w, c->d_geom.as<PyrGeom>(), c->geom,
+                      c->d_pyr.as<uint8_t>(), 1);
     for (int l = 1; l < c->geom.nlevels; l++)
-        launch_pyr_resize(c->stream, src, c->d_geom.as<PyrGeom>(), c->geom, c->d_pyr.as<uint8_t>(), l,
+        launch_pyr_resize(c->stream, c->d_geom.as<PyrGeom>(), c->geom, c->d_pyr.as<uint8_t>(), l,
                           c->d_coef.as<uint32_t>() + c->coef_x[l], c->d_coef.as<uint32_t>() + c->coef_y[l], 1);
     int* nkp = c->h_nkp.as<int>();
     nkp[0] = cnt;
@@ -422,7 +497,7 @@ int vo_orb_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, con
     VO_HIP(c, hipMemcpyAsync(c->d_nkp.p, nkp, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     VO_HIP(c, hipMemcpyAsync(c->d_kp.p, sorted.data(), (size_t)cnt * sizeof(vo_keypoint), hipMemcpyHostToDevice,
                              c->stream));
-    VO_TRY(feat_describe(c, src, 1, cnt, false));
+    VO_TRY(feat_describe(c, 1, cnt, false, false));
     VO_HIP(c, hipMemcpyAsync(desc, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(kp, sorted.data(), (size_t)cnt * sizeof(vo_keypoint));

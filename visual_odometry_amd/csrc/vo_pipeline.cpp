@@ -16,6 +16,40 @@ int match_filter_dev(vo_ctx* c, const vo_keypoint* d_kq, const vo_keypoint* d_kt
 
 
 
+// Everything after keypoint selection for the batch, asynchronous up to the final copy of the
+// results; max_n bounds the per-frame keypoint count (launch sizes, per-pair strides).
+static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const double* K, const vo_pair_params* prm) {
+    const int npairs = n_frames - 1;
+    const int n_cap = std::max(max_n, 8);
+    if (n_cap > c->lim.max_points)
+        return c->fail(VO_ERR_CAPACITY, "%d keypoints per frame exceed max_points %d", n_cap, c->lim.max_points);
+    const size_t kp_cap = (size_t)c->kp_cap;
+    VO_TRY(match_knn2_dev(c, c->d_desc.as<uint32_t>(), c->d_desc.as<uint32_t>() + kp_cap * 8, kp_cap * 8,
+                          kp_cap * 8, c->d_nkp.as<int>(), max_n, max_n, 8, npairs, n_cap));
+    VO_TRY(match_filter_dev(c, c->d_kp.as<vo_keypoint>(), c->d_kp.as<vo_keypoint>() + kp_cap, kp_cap,
+                            c->d_nkp.as<int>(), max_n, npairs, n_cap, prm->ratio, prm->max_disp));
+    VO_TRY(geom_prepare(c, npairs, n_cap, prm->seed, prm->max_iters));
+    VO_TRY(geom_find_essential_dev(c, npairs, n_cap, c->d_p0.as<float2>(), c->d_p1.as<float2>(),
+                                   c->d_ngood.as<int>(), 0, K, VO_RANSAC, prm->prob, prm->threshold,
+                                   prm->max_iters));
+    const double* d_E = reinterpret_cast<const double*>(c->d_state.as<char>() + offsetof(EstState, E));
+    VO_TRY(geom_recover_pose_dev(c, npairs, n_cap, d_E, sizeof(EstState) / sizeof(double), nullptr, nullptr,
+                                 c->d_ngood.as<int>(), 0, K, prm->dist_thresh, true));
+    VO_TRY(vo_ensure_pinned(c, c->h_state, (size_t)npairs * sizeof(EstState)));
+    VO_TRY(vo_ensure_pinned(c, c->h_pose, (size_t)npairs * sizeof(PoseState)));
+    VO_TRY(vo_ensure_pinned(c, c->h_good, (size_t)npairs * sizeof(int)));
+    VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, (size_t)npairs * sizeof(EstState), hipMemcpyDeviceToHost,
+                             c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, (size_t)npairs * sizeof(PoseState), hipMemcpyDeviceToHost,
+                             c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_good.p, c->d_ngood.p, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost,
+                             c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_nkp.p, c->d_nkp.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
+                             c->stream));
+    c->pipe_ncap = n_cap;
+    return VO_OK;
+}
+
 extern "C" {
 
 int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride,
@@ -31,49 +65,31 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
     const int npairs = n_frames - 1;
     c->pipe_frames = 0;
 
-    // ---- ORB on every frame ----------------------------------------------------------------
+    // ---- the whole batch is queued without a host round trip: ORB with the device-side keypoint
+    // selection, matching, essential matrix, pose; one synchronisation for the results ------------
     VO_TRY(feat_setup(c, w, h, &prm->orb, n_frames));
-    FrameSrc src;
-    src.img = d_frames;
-    src.frame_stride = frame_stride;
-    src.stride = stride;
-    src.pyr = nullptr;
-    VO_TRY(feat_detect(c, src, n_frames, prm->orb.fast_threshold, prm->orb.edge_threshold, 1, 1));
-    int max_n = 0;
-    VO_TRY(feat_select_orb(c, n_frames, &max_n));
-    c->pipe_nkp.assign(c->h_nkp.as<int>(), c->h_nkp.as<int>() + n_frames);
-    if (max_n > 0) VO_TRY(feat_describe(c, src, n_frames, max_n, true));
-
-    // ---- match consecutive frames ------------------------------------------------------------
-    const int n_cap = std::max(max_n, 8);
-    if (n_cap > c->lim.max_points)
-        return c->fail(VO_ERR_CAPACITY, "%d keypoints per frame exceed max_points %d", n_cap, c->lim.max_points);
-    const size_t kp_cap = (size_t)c->kp_cap;
-    VO_TRY(match_knn2_dev(c, c->d_desc.as<uint32_t>(), c->d_desc.as<uint32_t>() + kp_cap * 8, kp_cap * 8,
-                          kp_cap * 8, c->d_nkp.as<int>(), max_n, max_n, 8, npairs, n_cap));
-    VO_TRY(match_filter_dev(c, c->d_kp.as<vo_keypoint>(), c->d_kp.as<vo_keypoint>() + kp_cap, kp_cap,
-                            c->d_nkp.as<int>(), max_n, npairs, n_cap, prm->ratio, prm->max_disp));
-
-    // ---- essential matrix + pose ----------------------------------------------------------------
-    VO_TRY(geom_prepare(c, npairs, n_cap, prm->seed, prm->max_iters));
-    VO_TRY(geom_find_essential_dev(c, npairs, n_cap, c->d_p0.as<float2>(), c->d_p1.as<float2>(),
-                                   c->d_ngood.as<int>(), 0, K, VO_RANSAC, prm->prob, prm->threshold,
-                                   prm->max_iters));
-    const double* d_E = reinterpret_cast<const double*>(c->d_state.as<char>() + offsetof(EstState, E));
-    VO_TRY(geom_recover_pose_dev(c, npairs, n_cap, d_E, sizeof(EstState) / sizeof(double), nullptr, nullptr,
-                                 c->d_ngood.as<int>(), 0, K, prm->dist_thresh, true));
-
-    // ---- results ---------------------------------------------------------------------------
-    VO_TRY(vo_ensure_pinned(c, c->h_state, (size_t)npairs * sizeof(EstState)));
-    VO_TRY(vo_ensure_pinned(c, c->h_pose, (size_t)npairs * sizeof(PoseState)));
-    VO_TRY(vo_ensure_pinned(c, c->h_good, (size_t)npairs * sizeof(int)));
-    VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, (size_t)npairs * sizeof(EstState), hipMemcpyDeviceToHost,
-                             c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, (size_t)npairs * sizeof(PoseState), hipMemcpyDeviceToHost,
-                             c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_good.p, c->d_ngood.p, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost,
+    VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
+                       prm->orb.edge_threshold, 1));
+    const int n_bound = feat_n_bound(c, prm->orb.nfeatures);
+    VO_TRY(feat_select_dev(c, n_frames, n_bound));
+    VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
+    VO_TRY(pairs_after_selection(c, n_frames, n_bound, K, prm));
+    VO_HIP(c, hipMemcpyAsync(c->h_flags.p, c->d_flags.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    int flagged = 0;
+    for (int f = 0; f < n_frames; f++) flagged |= c->h_flags.as<int>()[f];
+    c->last_flags = flagged;
+    if (flagged) {
+        // a frame the device selection could not finish exactly (VO_SEL_*): host selection, redo
+        int max_n = 0;
+        VO_TRY(feat_select_host(c, n_frames, &max_n));
+        if (max_n > 0) VO_TRY(feat_describe(c, n_frames, max_n, true, true));
+        VO_TRY(pairs_after_selection(c, n_frames, max_n, K, prm));
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->pipe_nkp.assign(c->h_nkp.as<int>(), c->h_nkp.as<int>() + n_frames);
+
     const EstState* es = c->h_state.as<EstState>();
     const PoseState* ps = c->h_pose.as<PoseState>();
     const int* ng = c->h_good.as<int>();
@@ -96,8 +112,6 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
         }
     }
     c->pipe_frames = n_frames;
-
-    c->pipe_ncap = n_cap;
     return VO_OK;
 }
 
