@@ -4,8 +4,9 @@
 Workload (BASELINE.json configs[1], batched): consecutive synthetic KITTI-shaped 1241x376 gray
 frames, ORB nfeatures=2000 detect+describe on every frame, brute-force Hamming 2-NN + ratio 0.7 +
 200 px gate between consecutive frames, findEssentialMat(RANSAC, 0.999, 1.0, seed (uint64)-1),
-recoverPose(200) — i.e. vo_pairs_run_dev().  A step = one pass over one batch of `--frames`
-frames (frames-1 frame pairs) that is already resident in HBM.  With N > 1 every rank runs its own
+recoverPose(200).  A step = one pass of vo_seq_run() over `--frames` frames (frames-1 frame pairs)
+already resident in HBM: the sequence runner cuts them into chunks of `--chunk` pairs and keeps
+`--streams` chunks in flight on separate HIP streams (each chunk is one vo_pairs_run_dev batch).  With N > 1 every rank runs its own
 synthetic sequence (sequences are the shard unit, no data-path collective; weak scaling) and the
 trajectories are gathered with one all_gather over RCCL after the timed region.
 
@@ -62,17 +63,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=33, help="frames per batch (pairs = frames - 1)")
+    ap.add_argument("--streams", type=int, default=3, help="chunks in flight (HIP streams)")
+    ap.add_argument("--chunk", type=int, default=32, help="frame pairs per chunk")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step (default streams*chunk + 1)")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
     args = ap.parse_args()
 
-    import torch
+    if args.frames <= 0:
+        args.frames = args.streams * args.chunk + 1
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # ---- synthetic input: each rank renders its own sequence (the shard unit); rendered in forked
+    # workers before anything touches the GPU ------------------------------------------------------
+    from visual_odometry_amd import synth
+
+    frames, poses, K = synth.make_sequence(rank, args.frames, workers=max(1, min(8, 16 // max(world, 1))))
+
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -82,19 +95,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from visual_odometry_amd import api, shard, synth
+    from visual_odometry_amd import api, shard
 
-    # ---- synthetic input: each rank renders its own sequence (the shard unit) ----------------
-    frames, poses, K = synth.make_sequence(rank, args.frames)
     n, h, w = frames.shape
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
-    ctx = api.VoContext(local_rank, max_batch=max(64, args.frames))
+    seq = api.VoSequence(local_rank, n_streams=args.streams, pairs_per_chunk=args.chunk)
+    ctx = seq.ctx(0)
     params = api.pair_params(args.nfeatures)
 
     def step():
-        return ctx.pairs_run_dev(d_frames.data_ptr(), n, w, h, w, w * h, K, params)
+        return seq.run(d_frames.data_ptr(), n, w, h, w, w * h, K, params)
 
     def barrier():
         if dist is not None:
@@ -109,6 +121,7 @@ def main():
         res = step()  # synchronous on return: results are on the host
     barrier()
     elapsed = time.perf_counter() - t0
+    seq_stats = seq.stats()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -124,13 +137,16 @@ def main():
         assert len(all_traj) == world
 
     # ---- roofline: matcher kernel, HIP events on the library's stream (untimed passes) ----------
+    # one chunk at a time on context 0, so that the matcher launch is timed without other streams
+    # sharing the chip (the rocprofv3 summary in profiles/ is taken with --streams 1 for the same reason)
     nkp = [res[0].n_kp0] + [res[p].n_kp1 for p in range(n - 1)]
-    algo_bytes = sum(scan_bytes(nkp[p], nkp[p + 1]) for p in range(n - 1))
+    nc = min(args.chunk, n - 1)  # pairs per matcher launch
+    algo_bytes = sum(scan_bytes(nkp[p], nkp[p + 1]) for p in range(nc))
     ctx.prof_enable(True)
     for which in (0, 1, 2):
         ctx.prof_get(which, True)
     for _ in range(5):
-        step()
+        ctx.pairs_run_dev(d_frames.data_ptr(), nc + 1, w, h, w, w * h, K, params)
     knn_n, knn_ms = ctx.prof_get(0)
     fast_n, fast_ms = ctx.prof_get(1)
     solve_n, solve_ms = ctx.prof_get(2)
@@ -149,7 +165,7 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "model": "O(N^2) scan model: nq*nt*32 + nq*32 + nq*16 bytes per pair (SURVEY.md 8d)",
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": knn_avg_s * 1e6,
-                "pairs_per_launch": n - 1}
+                "pairs_per_launch": nc}
 
     # ---- 8k x 8k matcher (BASELINE config 3 shape), same accounting -----------------------------
     matcher_8k = None
@@ -190,8 +206,10 @@ def main():
             "data": "synthetic (seeded planar-world KITTI-shaped frames rendered by visual_odometry_amd/synth.py)",
             "config": {"workload": "configs[1] batched: %d consecutive 1241x376 frames per GPU resident in HBM, "
                                    "ORB nfeatures=%d + BF-Hamming knn2/ratio/gate + 5-pt RANSAC + recoverPose per "
-                                   "consecutive pair" % (n, args.nfeatures),
+                                   "consecutive pair; chunks of %d pairs on %d HIP streams"
+                                   % (n, args.nfeatures, args.chunk, args.streams),
                        "frames_per_step": n, "pairs_per_step": pairs_per_step, "nfeatures": args.nfeatures,
+                       "streams": args.streams, "pairs_per_chunk": args.chunk,
                        "parallelism": "sequence shards x%d, no data-path collective" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -199,11 +217,12 @@ def main():
             "stage_us_per_step": {"fast_score_kernel": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
                                   "knn2_partial_kernel": knn_avg_s * 1e6,
                                   "solve5_kernels_per_step": solve_ms / 5 * 1e3},
+            "host_ms_last_step": {"chunks": seq_stats[0], "queueing": seq_stats[1], "waiting": seq_stats[2]},
             "pairs_with_pose": ok,
             "keypoints_per_frame": float(np.mean(nkp)),
         }
         print(json.dumps(line))
-    ctx.close()
+    seq.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -147,6 +147,31 @@ int vo_pairs_get_frame(vo_ctx* ctx, int frame, vo_keypoint* kp, uint8_t* desc, i
 int vo_pairs_get_matches(vo_ctx* ctx, int pair, vo_dmatch* good, uint8_t* inlier_mask,
                          uint8_t* pose_mask, int cap, int* n);
 
+/* ---- sequence runner (BASELINE.json configs[3]: a whole sequence pipelined on one GPU) ------
+ * Replaces the front-end work of the per-image loop (reference: src/main.cpp:59-66 ->
+ * VisualOdometry::addImage, src/visual_odometry/visual_odometry.cpp:20-68) for the descriptor
+ * path: n_frames consecutive frames in, one vo_pair_result per consecutive pair out, identical to
+ * what vo_pairs_run_dev returns for the same frames.  The sequence is cut into chunks of
+ * pairs_per_chunk pairs (neighbouring chunks share a frame); chunk k runs on stream k mod n_streams
+ * with its own workspace, so uploads and the latency-bound stages of one chunk overlap the
+ * streaming stages of the others.  `mem` says where `frames` lives: VO_MEM_DEVICE (HBM),
+ * VO_MEM_HOST (pageable; staged through pinned memory) or VO_MEM_HOST_PINNED (hipHostMalloc'ed /
+ * registered memory; copied by DMA directly).  Not thread-safe; one runner per host thread. */
+#define VO_MEM_HOST 0
+#define VO_MEM_DEVICE 1
+#define VO_MEM_HOST_PINNED 2
+typedef struct vo_seq vo_seq;
+int vo_seq_create(int device, const vo_limits* limits, int n_streams, int pairs_per_chunk, vo_seq** out);
+void vo_seq_destroy(vo_seq* s);
+const char* vo_seq_last_error(const vo_seq* s);
+int vo_seq_streams(const vo_seq* s);
+/* context i of the runner (owned by the runner): for the measurement hooks and vo_ctx_*_option */
+vo_ctx* vo_seq_ctx(vo_seq* s, int i);
+/* host time of the last vo_seq_run spent queueing work (submit) and waiting for results (wait) */
+int vo_seq_get_stats(const vo_seq* s, int* chunks, double* submit_ms, double* wait_ms);
+int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
+               size_t frame_stride, const double* K, const vo_pair_params* params, vo_pair_result* results);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------
  * When enabled, launches of the matcher kernel are bracketed with HIP events on the ctx stream;
  * vo_prof_get returns the number of launches and their summed duration since the last reset. */

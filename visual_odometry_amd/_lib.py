@@ -18,6 +18,7 @@ SYMBOLS = [
     "vo_knn2_hamming", "vo_match_filter", "vo_find_essential", "vo_recover_pose", "vo_triangulate",
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
     "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
+    "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_get_stats",
 ]
 
 
@@ -66,4 +67,11 @@ def lib():
         _lib.vo_last_error.argtypes = [C.c_void_p]
         _lib.vo_ctx_destroy.argtypes = [C.c_void_p]
         _lib.vo_ctx_destroy.restype = None
+        _lib.vo_seq_last_error.restype = C.c_char_p
+        _lib.vo_seq_last_error.argtypes = [C.c_void_p]
+        _lib.vo_seq_destroy.argtypes = [C.c_void_p]
+        _lib.vo_seq_destroy.restype = None
+        _lib.vo_seq_ctx.restype = C.c_void_p
+        _lib.vo_seq_ctx.argtypes = [C.c_void_p, C.c_int]
+        _lib.vo_seq_streams.argtypes = [C.c_void_p]
     return _lib

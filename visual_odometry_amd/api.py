@@ -245,3 +245,72 @@ class VoContext:
         ms = C.c_double(0)
         self._check(self.L.vo_prof_get(self.h, int(which), int(bool(reset)), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+
+MEM_HOST, MEM_DEVICE, MEM_HOST_PINNED = 0, 1, 2
+
+
+class _BorrowedContext(VoContext):
+    """A vo_ctx owned by a sequence runner (measurement hooks / options only)."""
+
+    def __init__(self, lib, handle, limits):
+        self.L = lib
+        self.h = C.c_void_p(handle)
+        self.limits = limits
+
+    def close(self):
+        self.h = None
+
+
+class VoSequence:
+    """vo_seq: a sequence pipelined over `n_streams` contexts in chunks of `pairs_per_chunk` pairs."""
+
+    def __init__(self, device=0, n_streams=4, pairs_per_chunk=32, **limits):
+        self.L = _lib.lib()
+        lim = Limits()
+        self.L.vo_limits_default(C.byref(lim))
+        for k, v in limits.items():
+            setattr(lim, k, v)
+        self.limits = lim
+        h = C.c_void_p()
+        rc = self.L.vo_seq_create(int(device), C.byref(lim), int(n_streams), int(pairs_per_chunk), C.byref(h))
+        if rc != 0:
+            raise VoError(rc, "vo_seq_create failed (no usable HIP device? there is no CPU fallback)")
+        self.h = h
+        self.n_streams = n_streams
+        self.pairs_per_chunk = pairs_per_chunk
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vo_seq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ctx(self, i=0):
+        return _BorrowedContext(self.L, self.L.vo_seq_ctx(self.h, int(i)), self.limits)
+
+    def stats(self):
+        """(chunks, host ms queueing, host ms waiting) of the last run."""
+        n, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        self.L.vo_seq_get_stats(self.h, C.byref(n), C.byref(a), C.byref(b))
+        return n.value, a.value, b.value
+
+    def run(self, frames, n_frames, w, h, stride, frame_stride, K, params, mem=MEM_DEVICE):
+        """frames: integer address (device or pinned host) or a uint8 numpy array (pageable host)."""
+        if isinstance(frames, np.ndarray):
+            assert frames.dtype == np.uint8 and frames.flags.c_contiguous
+            ptr = frames.ctypes.data_as(C.c_void_p)
+        else:
+            ptr = C.c_void_p(int(frames))
+        K = np.ascontiguousarray(K, np.float64)
+        res = (PairResult * max(n_frames - 1, 1))()
+        rc = self.L.vo_seq_run(self.h, ptr, int(mem), int(n_frames), int(w), int(h), int(stride),
+                               C.c_size_t(frame_stride), _p(K), C.byref(params), res)
+        if rc != 0:
+            raise VoError(rc, self.L.vo_seq_last_error(self.h).decode())
+        return res

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/vo_hip.h"
@@ -26,6 +27,16 @@ struct PinnedBuf {
     size_t cap = 0;
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// cv::RNG 5-subsets for every point count (uint16 [maxn + 1][iters][5]); depends only on
+// (seed, iters, maxn), so the contexts of one device share one copy.
+struct SampleTable {
+    int device = 0;
+    uint64_t seed = 0;
+    int iters = 0, maxn = 0;
+    void* p = nullptr;
+    ~SampleTable();
 };
 
 struct ProfSlot {
@@ -85,9 +96,7 @@ struct vo_ctx {
     PinnedBuf h_knn, h_good;
 
     // ---- geometry workspace ----------------------------------------------------------------
-    DevBuf d_samples;  // uint16 [max_points + 1][samples_iters][5] (+ pad)
-    int samples_max_n = 0, samples_iters = 0;
-    uint64_t samples_seed = 0;
+    std::shared_ptr<SampleTable> samples;  // uint16 [max_points + 1][iters][5]
     DevBuf d_x1, d_x2;   // double2 [pair][n_cap]: K-normalised points
     DevBuf d_models;     // double [pair][H][10][9]
     DevBuf d_nmodels;    // int [pair][H]
@@ -106,6 +115,9 @@ struct vo_ctx {
 
     // ---- vo_pairs_run_dev bookkeeping --------------------------------------------------------
     int pipe_frames = 0, pipe_ncap = 0;
+    int pend_frames = 0;  // frames of the batch queued by pairs_submit and not yet collected
+    double pend_K[9];
+    vo_pair_params pend_prm;
     std::vector<int> pipe_nkp;
     std::vector<int> pipe_ngood;
 
@@ -157,6 +169,11 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
 int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, size_t e_stride,
                           const float2* d_p0, const float2* d_p1, const int* d_n, int n_host,
                           const double* K, double dist_thresh, bool use_mask);
+
+// device-resident batch (vo_pipeline.cpp): queue everything / wait and fill the results
+int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
+                 const double* K, const vo_pair_params* prm);
+int pairs_collect(vo_ctx* c, vo_pair_result* results);
 
 // profiling bracket (no-ops unless vo_prof_enable(ctx, 1))
 struct ProfScope {

@@ -104,7 +104,7 @@ void vo_ctx_destroy(vo_ctx* c) {
                      &c->d_lvlofs, &c->d_cand,  &c->d_sel,   &c->d_coef,   &c->d_geom,   &c->d_kp,
                      &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,
                      &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,
-                     &c->d_samples, &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
+                     &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
                      &c->d_state, &c->d_mask,   &c->d_q4,    &c->d_cmask,  &c->d_pose,   &c->d_pmask,
                      &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj};
     for (DevBuf* b : dev)

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 #include <thread>
 
 #include "ctx.h"
@@ -54,31 +55,53 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)std::lrint(num / denom);
 }
 
+// One table per (device, seed, iters, maxn), shared by the contexts that ask for it.
+std::shared_ptr<SampleTable> samples_acquire(int device, uint64_t seed, int iters, int maxn) {
+    static std::mutex mu;
+    static std::vector<std::weak_ptr<SampleTable>> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& w : cache)
+        if (auto t = w.lock())
+            if (t->device == device && t->seed == seed && t->iters >= iters && t->maxn >= maxn) return t;
+    std::vector<uint16_t> tab((size_t)(maxn + 1) * iters * 5, 0);
+    const int nthreads = 8;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++)
+        th.emplace_back([&, t]() {
+            for (int n = 5 + t; n <= maxn; n += nthreads) fill_subsets(seed, n, iters, &tab[(size_t)n * iters * 5]);
+        });
+    for (auto& x : th) x.join();
+    auto t = std::make_shared<SampleTable>();
+    t->device = device;
+    t->seed = seed;
+    t->iters = iters;
+    t->maxn = maxn;
+    if (hipMalloc(&t->p, tab.size() * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(t->p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache.erase(std::remove_if(cache.begin(), cache.end(), [](const std::weak_ptr<SampleTable>& w) { return w.expired(); }),
+                cache.end());
+    cache.push_back(t);
+    return t;
+}
+
 }  // namespace
+
+SampleTable::~SampleTable() {
+    if (p) {
+        (void)hipSetDevice(device);
+        (void)hipFree(p);
+    }
+}
 
 // Sample table + per-pair workspace for npairs problems of up to n_cap points, H hypotheses.
 int geom_prepare(vo_ctx* c, int npairs, int n_cap, uint64_t seed, int H) {
     if (n_cap > c->lim.max_points)
         return c->fail(VO_ERR_CAPACITY, "%d points exceed max_points %d", n_cap, c->lim.max_points);
     if (H < 1 || H > 65536) return c->fail(VO_ERR_INVALID, "max_iters %d out of range", H);
-    if (c->samples_seed != seed || c->samples_iters < H || c->samples_max_n < c->lim.max_points || !c->d_samples.p) {
-        const int iters = std::max(H, 1000);
-        const int maxn = c->lim.max_points;
-        std::vector<uint16_t> tab((size_t)(maxn + 1) * iters * 5, 0);
-        const int nthreads = 8;
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; t++)
-            th.emplace_back([&, t]() {
-                for (int n = 5 + t; n <= maxn; n += nthreads)
-                    fill_subsets(seed, n, iters, &tab[(size_t)n * iters * 5]);
-            });
-        for (auto& x : th) x.join();
-        VO_HIP(c, hipStreamSynchronize(c->stream));
-        VO_TRY(vo_ensure(c, c->d_samples, tab.size() * sizeof(uint16_t)));
-        VO_HIP(c, hipMemcpy(c->d_samples.p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        c->samples_seed = seed;
-        c->samples_iters = iters;
-        c->samples_max_n = maxn;
+    if (!c->samples || c->samples->seed != seed || c->samples->iters < H || c->samples->maxn < c->lim.max_points) {
+        VO_HIP(c, hipStreamSynchronize(c->stream));  // the stream may still read the old table
+        c->samples = samples_acquire(c->device, seed, std::max(H, 1000), c->lim.max_points);
+        if (!c->samples) return c->fail(VO_ERR_DEVICE, "could not build the RANSAC sample table");
     }
     const size_t np = (size_t)npairs;
     VO_TRY(vo_ensure(c, c->d_x1, np * n_cap * sizeof(double2)));
@@ -115,7 +138,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
     double2* x2 = c->d_x2.as<double2>();
     double* models = c->d_models.as<double>();
     int* nmodels = c->d_nmodels.as<int>();
-    const uint16_t* samples = c->d_samples.as<uint16_t>();
+    const uint16_t* samples = reinterpret_cast<const uint16_t*>(c->samples->p);
     const int n_grid = d_n ? n_cap : n_host;
 
     launch_est_init(st, S, d_n, n_host, n_cap, niters, thr_f, npairs);
@@ -129,7 +152,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
             const int h1 = std::min(H, h0 + size);
             {
                 ProfScope ps(c, VO_PROF_SOLVE);
-                launch_solve5(st, h0, h1, S, samples, c->samples_iters, x1, x2, n_cap, models, nmodels, H, npairs);
+                launch_solve5(st, h0, h1, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs);
             }
             launch_score(st, h0, h1, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<int>(), H, npairs);
             launch_replay(st, h0, h1, S, nmodels, c->d_counts.as<int>(), H, prob, npairs);
@@ -139,7 +162,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
     } else {
         {
             ProfScope ps(c, VO_PROF_SOLVE);
-            launch_solve5(st, 0, niters, S, samples, c->samples_iters, x1, x2, n_cap, models, nmodels, H, npairs);
+            launch_solve5(st, 0, niters, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs);
         }
         launch_lmeds(st, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<double>(), H, niters, npairs);
     }

@@ -4,6 +4,8 @@
 // (reference: src/visual_odometry/vo_pose.h:19).  Frames stay in HBM; the host sees one
 // synchronisation for the keypoint selection (vo_features.cpp) and one for the results.
 #include <algorithm>
+#include <cstdarg>
+#include <chrono>
 #include <cstddef>
 
 #include "ctx.h"
@@ -50,23 +52,19 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
     return VO_OK;
 }
 
-extern "C" {
-
-int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride,
-                     size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results) {
-    if (!c) return VO_ERR_INVALID;
+// Queue the whole batch on the context's stream without a host round trip: ORB with the
+// device-side keypoint selection, matching, essential matrix, pose, result copies.
+int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
+                 const double* K, const vo_pair_params* prm) {
     if (!d_frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
-        !prm || !results)
+        !prm)
         return c->fail(VO_ERR_INVALID, "vo_pairs_run_dev: bad argument");
     if (prm->orb.nfeatures > c->lim.max_features)
         return c->fail(VO_ERR_CAPACITY, "nfeatures %d exceeds max_features %d", prm->orb.nfeatures,
                        c->lim.max_features);
     VO_HIP(c, hipSetDevice(c->device));
-    const int npairs = n_frames - 1;
     c->pipe_frames = 0;
-
-    // ---- the whole batch is queued without a host round trip: ORB with the device-side keypoint
-    // selection, matching, essential matrix, pose; one synchronisation for the results ------------
+    c->pend_frames = 0;
     VO_TRY(feat_setup(c, w, h, &prm->orb, n_frames));
     VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
                        prm->orb.edge_threshold, 1));
@@ -76,6 +74,19 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
     VO_TRY(pairs_after_selection(c, n_frames, n_bound, K, prm));
     VO_HIP(c, hipMemcpyAsync(c->h_flags.p, c->d_flags.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
+    memcpy(c->pend_K, K, sizeof(c->pend_K));
+    c->pend_prm = *prm;
+    c->pend_frames = n_frames;
+    return VO_OK;
+}
+
+// Wait for the batch queued by pairs_submit and fill results[n_frames - 1].
+int pairs_collect(vo_ctx* c, vo_pair_result* results) {
+    const int n_frames = c->pend_frames;
+    if (n_frames < 2 || !results) return c->fail(VO_ERR_INVALID, "no batch is pending");
+    VO_HIP(c, hipSetDevice(c->device));
+    c->pend_frames = 0;
+    const int npairs = n_frames - 1;
     VO_HIP(c, hipStreamSynchronize(c->stream));
     int flagged = 0;
     for (int f = 0; f < n_frames; f++) flagged |= c->h_flags.as<int>()[f];
@@ -85,7 +96,7 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
         int max_n = 0;
         VO_TRY(feat_select_host(c, n_frames, &max_n));
         if (max_n > 0) VO_TRY(feat_describe(c, n_frames, max_n, true, true));
-        VO_TRY(pairs_after_selection(c, n_frames, max_n, K, prm));
+        VO_TRY(pairs_after_selection(c, n_frames, max_n, c->pend_K, &c->pend_prm));
         VO_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->pipe_nkp.assign(c->h_nkp.as<int>(), c->h_nkp.as<int>() + n_frames);
@@ -113,6 +124,175 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
     }
     c->pipe_frames = n_frames;
     return VO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequence runner: a long sequence cut into chunks of `chunk_pairs` frame pairs (consecutive chunks
+// share one frame), chunk k on context k mod n_streams.  Every context has its own HIP stream and
+// workspace, so the latency-bound stages of one chunk (keypoint selection, five-point solves,
+// RANSAC replay) run while the other chunks' streaming stages use the rest of the chip, and the
+// upload of a chunk overlaps the kernels of the chunks before it.
+// ---------------------------------------------------------------------------------------------
+struct vo_seq {
+    int device = 0;
+    int chunk_pairs = 32;
+    std::vector<vo_ctx*> ctx;
+    std::vector<PinnedBuf> stage;  // per context: pinned staging of one chunk (pageable input)
+    double submit_ms = 0, wait_ms = 0;  // host time of the last vo_seq_run spent queueing / waiting
+    int chunks = 0;
+    char err[512];
+    int fail(int code, const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(err, sizeof(err), fmt, ap);
+        va_end(ap);
+        return code;
+    }
+    int from(vo_ctx* c, int rc) {
+        if (rc != VO_OK) snprintf(err, sizeof(err), "%s", c->err);
+        return rc;
+    }
+};
+
+extern "C" {
+
+int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride,
+                     size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results) {
+    if (!c) return VO_ERR_INVALID;
+    if (!results) return c->fail(VO_ERR_INVALID, "vo_pairs_run_dev: bad argument");
+    VO_TRY(pairs_submit(c, d_frames, n_frames, w, h, stride, frame_stride, K, prm));
+    return pairs_collect(c, results);
+}
+
+int vo_seq_create(int device, const vo_limits* limits, int n_streams, int pairs_per_chunk, vo_seq** out) {
+    if (!out) return VO_ERR_INVALID;
+    *out = nullptr;
+    if (n_streams < 1 || n_streams > 16 || pairs_per_chunk < 1) return VO_ERR_INVALID;
+    vo_limits lim;
+    if (limits) lim = *limits;
+    else vo_limits_default(&lim);
+    lim.max_batch = std::max(lim.max_batch, pairs_per_chunk + 1);
+    vo_seq* s = new vo_seq();
+    s->device = device;
+    s->chunk_pairs = pairs_per_chunk;
+    s->err[0] = 0;
+    s->stage.resize(n_streams);
+    for (int i = 0; i < n_streams; i++) {
+        vo_ctx* c = nullptr;
+        const int rc = vo_ctx_create(device, &lim, &c);
+        if (rc != VO_OK) {
+            vo_seq_destroy(s);
+            return rc;
+        }
+        s->ctx.push_back(c);
+    }
+    *out = s;
+    return VO_OK;
+}
+
+void vo_seq_destroy(vo_seq* s) {
+    if (!s) return;
+    for (size_t i = 0; i < s->ctx.size(); i++) {
+        (void)hipSetDevice(s->device);
+        (void)hipStreamSynchronize(s->ctx[i]->stream);
+        if (s->stage[i].p) (void)hipHostFree(s->stage[i].p);
+        vo_ctx_destroy(s->ctx[i]);
+    }
+    delete s;
+}
+
+const char* vo_seq_last_error(const vo_seq* s) { return s ? s->err : "null sequence runner"; }
+
+int vo_seq_streams(const vo_seq* s) { return s ? (int)s->ctx.size() : 0; }
+
+int vo_seq_get_stats(const vo_seq* s, int* chunks, double* submit_ms, double* wait_ms) {
+    if (!s) return VO_ERR_INVALID;
+    if (chunks) *chunks = s->chunks;
+    if (submit_ms) *submit_ms = s->submit_ms;
+    if (wait_ms) *wait_ms = s->wait_ms;
+    return VO_OK;
+}
+
+vo_ctx* vo_seq_ctx(vo_seq* s, int i) { return (s && i >= 0 && i < (int)s->ctx.size()) ? s->ctx[i] : nullptr; }
+
+int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
+               size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results) {
+    if (!s) return VO_ERR_INVALID;
+    if (!frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
+        !prm || !results || (mem != VO_MEM_HOST && mem != VO_MEM_DEVICE && mem != VO_MEM_HOST_PINNED))
+        return s->fail(VO_ERR_INVALID, "vo_seq_run: bad argument");
+    if (hipSetDevice(s->device) != hipSuccess) return s->fail(VO_ERR_DEVICE, "hipSetDevice(%d) failed", s->device);
+    const int S = (int)s->ctx.size(), B = s->chunk_pairs;
+    const int npairs = n_frames - 1;
+    const int nchunks = (npairs + B - 1) / B;
+    const size_t img = (size_t)w * h;
+    int rc = VO_OK;
+    int collected = 0;  // chunks [0, collected) have their results
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    s->submit_ms = s->wait_ms = 0;
+    s->chunks = nchunks;
+    auto collect = [&](int k) {
+        const auto t0 = clk::now();
+        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], results + (size_t)k * B));
+        s->wait_ms += ms_since(t0);
+        return r;
+    };
+    for (int k = 0; k < nchunks && rc == VO_OK; k++) {
+        const int slot = k % S;
+        vo_ctx* c = s->ctx[slot];
+        if (k - S >= collected) {  // the context still holds chunk k - S
+            rc = collect(k - S);
+            collected = k - S + 1;
+            if (rc != VO_OK) break;
+        }
+        const int f0 = k * B, nf = std::min(B, npairs - f0) + 1;
+        const uint8_t* src = frames + (size_t)f0 * frame_stride;
+        const auto t_submit = clk::now();
+        struct Acc {
+            vo_seq* s;
+            clk::time_point t0;
+            ~Acc() { s->submit_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+        } acc{s, t_submit};
+        if (mem == VO_MEM_DEVICE) {
+            rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm));
+            continue;
+        }
+        // host frames: tightly packed copy of the chunk into the context's image buffer
+        if ((rc = s->from(c, vo_ensure(c, c->d_img, (size_t)(B + 1) * img))) != VO_OK) break;
+        hipError_t e = hipSuccess;
+        if (mem == VO_MEM_HOST) {
+            // pageable memory: stage through pinned memory so that the copy is one asynchronous DMA
+            if ((rc = s->from(c, vo_ensure_pinned(c, s->stage[slot], (size_t)(B + 1) * img))) != VO_OK) break;
+            uint8_t* st = s->stage[slot].as<uint8_t>();
+            for (int f = 0; f < nf; f++)
+                for (int y = 0; y < h; y++)
+                    memcpy(st + (size_t)f * img + (size_t)y * w, src + (size_t)f * frame_stride + (size_t)y * stride, w);
+            e = hipMemcpyAsync(c->d_img.p, st, (size_t)nf * img, hipMemcpyHostToDevice, c->stream);
+        } else if (stride == w && frame_stride == img) {
+            e = hipMemcpyAsync(c->d_img.p, src, (size_t)nf * img, hipMemcpyHostToDevice, c->stream);
+        } else {
+            for (int f = 0; f < nf && e == hipSuccess; f++)
+                e = hipMemcpy2DAsync(c->d_img.as<uint8_t>() + (size_t)f * img, w, src + (size_t)f * frame_stride, stride,
+                                     w, h, hipMemcpyHostToDevice, c->stream);
+        }
+        if (e != hipSuccess) {
+            rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(e));
+            break;
+        }
+        rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm));
+    }
+    // drain in order (also after an error, so that no context is left with work in flight)
+    for (int k = collected; k < nchunks; k++) {
+        vo_ctx* c = s->ctx[k % S];
+        if (c->pend_frames < 2) continue;
+        if (rc == VO_OK) rc = collect(k);
+        else {
+            (void)hipStreamSynchronize(c->stream);
+            c->pend_frames = 0;
+        }
+    }
+    return rc;
 }
 
 int vo_pairs_get_frame(vo_ctx* c, int frame, vo_keypoint* kp, uint8_t* desc, int cap, int* n) {

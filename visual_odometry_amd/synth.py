@@ -121,11 +121,31 @@ class World:
         return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def make_sequence(seq_id, n_frames, w=KITTI_W, h=KITTI_H, K=KITTI_K):
-    """Returns (frames uint8 (n,h,w), poses (n,3,4) camera-to-world, K)."""
+_render_job = None
+
+
+def _render_one(k):
+    world, poses, K, w, h = _render_job
+    return world.render(poses[k], K, w, h)
+
+
+def make_sequence(seq_id, n_frames, w=KITTI_W, h=KITTI_H, K=KITTI_K, workers=1):
+    """Returns (frames uint8 (n,h,w), poses (n,3,4) camera-to-world, K).
+
+    workers > 1 renders the frames in forked worker processes (same pixels; call it before the
+    process touches the GPU)."""
+    global _render_job
     world = World(seq_id)
     poses = trajectory(seq_id, n_frames)
-    frames = np.stack([world.render(poses[k], K, w, h) for k in range(n_frames)])
+    if workers > 1 and n_frames > 8:
+        import multiprocessing as mp
+
+        _render_job = (world, poses, K, w, h)
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = np.stack(pool.map(_render_one, range(n_frames), chunksize=4))
+        _render_job = None
+    else:
+        frames = np.stack([world.render(poses[k], K, w, h) for k in range(n_frames)])
     return frames, poses, K.copy()
 
 
