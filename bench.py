@@ -158,10 +158,11 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path))["kernels"]["k_knn2_partial<4>"]["hbm_bytes"]
+            kern = json.load(open(pmc_path))["kernels"]
+            traffic = [v for k, v in kern.items() if k.startswith("k_knn2_partial")][0]["hbm_bytes"]
         except Exception:
             traffic = None
-    roofline = {"kernel": "k_knn2_partial<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    roofline = {"kernel": "k_knn2_partial<8, 1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "model": "O(N^2) scan model: nq*nt*32 + nq*32 + nq*16 bytes per pair (SURVEY.md 8d)",
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": knn_avg_s * 1e6,

@@ -1,0 +1,29 @@
+"""Matcher kernel timing: 8192 x 8192 single launch and the 32-pair 2k batch (HIP events via vo_prof)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from visual_odometry_amd import api, synth
+
+frames, poses, K = synth.make_sequence(0, 33, workers=8)
+import torch
+d = torch.from_numpy(frames).to("cuda:0")
+ctx = api.VoContext(0)
+q, t = synth.matcher_descriptors(8192)
+for _ in range(2):
+    ctx.knn2_hamming(q, t)
+ctx.prof_enable(True); ctx.prof_get(0, True)
+for _ in range(10):
+    ctx.knn2_hamming(q, t)
+n, ms = ctx.prof_get(0)
+us8 = ms / n * 1e3
+n_, h, w = frames.shape
+prm = api.pair_params(2000)
+for _ in range(2):
+    ctx.pairs_run_dev(d.data_ptr(), n_, w, h, w, w * h, K, prm)
+ctx.prof_get(0, True)
+for _ in range(10):
+    ctx.pairs_run_dev(d.data_ptr(), n_, w, h, w, w * h, K, prm)
+n, ms = ctx.prof_get(0)
+us2 = ms / n * 1e3
+print("Q=%s S=%s  8k: %.1f us (%.2f Tpairs/s)   32x2k: %.1f us (%.2f Tpairs/s)" % (
+    os.environ.get("VO_KNN_Q"), os.environ.get("VO_KNN_SPLITS"), us8, 8192 * 8192 / us8 / 1e6, us2, 32 * 4e6 / us2 / 1e6))

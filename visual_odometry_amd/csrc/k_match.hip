@@ -12,49 +12,100 @@
 
 #define KNN_TILE 256  // train descriptors per LDS tile
 
-template <int W64>  // u64 words per descriptor: 4 (32 B) or 8 (64 B)
+// W32: uint32 words per descriptor (8 or 16); Q: queries per lane.  A block of 256 threads owns
+// 256 * Q queries (query i of a lane is q0 + i * 256 + thread) and scans rows [tbeg, tend) of the
+// train set.  The tile for the next step is fetched into registers while the current one is
+// scanned (two LDS buffers, one barrier per tile).  Per (query, row): W32 xor + W32 bcnt (the
+// popcount instruction accumulates) + key pack + min / max / min.
+template <int W32, int Q>
 __global__ __launch_bounds__(256) void k_knn2_partial(KnnArgs a) {
-    __shared__ unsigned long long tile[KNN_TILE * W64];
+    constexpr int V = W32 / 4;                   // uint4 per descriptor
+    constexpr int LD = KNN_TILE * V / 256;       // uint4 per thread per tile
+    __shared__ uint4 tile[2][KNN_TILE * V];
     const int pair = blockIdx.z;
     const int nq = a.d_n ? a.d_n[pair] : a.nq;
     const int nt = a.d_n ? a.d_n[pair + 1] : a.nt;
-    const int q0 = blockIdx.x * 256;
+    const int q0 = blockIdx.x * (256 * Q);
     if (q0 >= nq) return;
-    const int qi = q0 + threadIdx.x;
-    const unsigned long long* Q = reinterpret_cast<const unsigned long long*>(a.q + pair * a.q_stride);
-    const unsigned long long* T = reinterpret_cast<const unsigned long long*>(a.t + pair * a.t_stride);
+    const uint4* Qp = reinterpret_cast<const uint4*>(a.q + pair * a.q_stride);
+    const uint4* T = reinterpret_cast<const uint4*>(a.t + pair * a.t_stride);
 
-    unsigned long long qv[W64];
-    {
-        const int qr = min(qi, nq - 1);
+    uint32_t qv[Q][W32];
 #pragma unroll
-        for (int k = 0; k < W64; k++) qv[k] = Q[(size_t)qr * W64 + k];
+    for (int i = 0; i < Q; i++) {
+        const int qr = min(q0 + i * 256 + (int)threadIdx.x, nq - 1);
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const uint4 v = Qp[(size_t)qr * V + k];
+            qv[i][4 * k] = v.x;
+            qv[i][4 * k + 1] = v.y;
+            qv[i][4 * k + 2] = v.z;
+            qv[i][4 * k + 3] = v.w;
+        }
     }
     const int chunk = cdiv(nt, a.splits);
     const int tbeg = blockIdx.y * chunk;
     const int tend = min(nt, tbeg + chunk);
-    uint32_t k1 = VO_KEY_INVALID, k2 = VO_KEY_INVALID;
+    uint32_t k1[Q], k2[Q];
+#pragma unroll
+    for (int i = 0; i < Q; i++) k1[i] = k2[i] = VO_KEY_INVALID;
 
+    uint4 nxt[LD];
+    auto fetch = [&](int base) {
+        const int cnt = min(KNN_TILE, tend - base) * V;
+#pragma unroll
+        for (int r = 0; r < LD; r++) {
+            const int i = r * 256 + threadIdx.x;
+            nxt[r] = i < cnt ? T[(size_t)base * V + i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < LD; r++) tile[buf][r * 256 + threadIdx.x] = nxt[r];
+    };
+    int buf = 0;
+    if (tbeg < tend) {
+        fetch(tbeg);
+        stash(0);
+    }
+    __syncthreads();
     for (int base = tbeg; base < tend; base += KNN_TILE) {
         const int n = min(KNN_TILE, tend - base);
-        __syncthreads();
-        // coalesced tile load: W64 u64 per row, rows contiguous in memory
-        for (int i = threadIdx.x; i < n * W64; i += 256) tile[i] = T[(size_t)base * W64 + i];
-        __syncthreads();
-#pragma unroll 4
+        const bool more = base + KNN_TILE < tend;
+        if (more) fetch(base + KNN_TILE);
+        const uint4* tl = tile[buf];
+#pragma unroll 2
         for (int j = 0; j < n; j++) {
-            const unsigned long long* tr = &tile[j * W64];
-            int d = 0;
+            uint32_t tr[W32];
 #pragma unroll
-            for (int k = 0; k < W64; k++) d += __popcll(qv[k] ^ tr[k]);
-            const uint32_t key = ((uint32_t)d << VO_KEY_SHIFT) | (uint32_t)(base + j);
-            const uint32_t lo = min(key, k1), hi = max(key, k1);
-            k2 = min(k2, hi);
-            k1 = lo;
+            for (int k = 0; k < V; k++) {
+                const uint4 v = tl[j * V + k];
+                tr[4 * k] = v.x;
+                tr[4 * k + 1] = v.y;
+                tr[4 * k + 2] = v.z;
+                tr[4 * k + 3] = v.w;
+            }
+            const uint32_t idx = (uint32_t)(base + j);
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int k = 0; k < W32; k++) d += __builtin_popcount(qv[i][k] ^ tr[k]);
+                const uint32_t key = (d << VO_KEY_SHIFT) | idx;
+                const uint32_t hi = max(key, k1[i]);
+                k1[i] = min(key, k1[i]);
+                k2[i] = min(k2[i], hi);
+            }
         }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
-    if (qi < nq)
-        a.part[((size_t)pair * a.splits + blockIdx.y) * a.nq_cap + qi] = make_uint2(k1, k2);
+#pragma unroll
+    for (int i = 0; i < Q; i++) {
+        const int qi = q0 + i * 256 + threadIdx.x;
+        if (qi < nq) a.part[((size_t)pair * a.splits + blockIdx.y) * a.nq_cap + qi] = make_uint2(k1[i], k2[i]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_knn2_merge(KnnArgs a) {
@@ -78,11 +129,17 @@ __global__ __launch_bounds__(256) void k_knn2_merge(KnnArgs a) {
 
 void launch_knn2_partial(hipStream_t st, const KnnArgs& a) {
     if (a.nq <= 0 || a.npairs <= 0) return;
-    dim3 grid(cdiv(a.nq, 256), a.splits, a.npairs);
-    if (a.words == 8)
-        hipLaunchKernelGGL(k_knn2_partial<4>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(k_knn2_partial<8>, grid, dim3(256), 0, st, a);
+    dim3 grid(cdiv(a.nq, 256 * a.qpl), a.splits, a.npairs);
+#define VO_KNN(W, QQ) hipLaunchKernelGGL((k_knn2_partial<W, QQ>), grid, dim3(256), 0, st, a)
+    if (a.words == 8) {
+        if (a.qpl == 4) VO_KNN(8, 4);
+        else if (a.qpl == 2) VO_KNN(8, 2);
+        else VO_KNN(8, 1);
+    } else {
+        if (a.qpl >= 2) VO_KNN(16, 2);
+        else VO_KNN(16, 1);
+    }
+#undef VO_KNN
 }
 
 void launch_knn2_merge(hipStream_t st, const KnnArgs& a) {

@@ -97,6 +97,7 @@ struct KnnArgs {
     int nq, nt;           // used when d_n == nullptr; otherwise upper bounds for the grid
     int words;            // 8 (32-byte descriptors) or 16 (64-byte)
     int splits;           // train range split across blockIdx.y
+    int qpl;              // queries per lane (1, 2 or 4; 64-byte rows: 1 or 2)
     uint2* part;          // [pair][split][nq_cap] partial top-2 keys
     uint2* knn;           // [pair][nq_cap] merged keys
     int nq_cap;

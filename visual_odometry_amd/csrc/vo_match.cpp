@@ -1,15 +1,17 @@
 // vo_match.cpp — host side of the matcher entry points (knnMatch(k=2) + ratio/displacement
 // filter).  Replaces the cv calls in matcher() (reference: src/matcher/matcher.cpp:10,17,23-38).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ctx.h"
 
-// Split count for the train range: enough blocks to cover the chip, chunks of >= 64 rows.
-static int knn_splits(int nq, int nt, int npairs) {
-    const int qblocks = cdiv(std::max(nq, 1), 256) * std::max(npairs, 1);
-    int s = cdiv(1024, qblocks);  // aim at ~4 blocks per CU
+// Split count for the train range: many short blocks balance best on 256 CUs (measured on MI355X,
+// gpurun_out/knn_sweep.log: 32 x 2k pairs 82.8 us at 1024 blocks, 75.3 us at 8192), chunks of >= 64 rows.
+static int knn_splits(int nq, int nt, int npairs, int qpl) {
+    const int qblocks = cdiv(std::max(nq, 1), 256 * qpl) * std::max(npairs, 1);
+    int s = cdiv(8192, qblocks);
     s = std::min(s, cdiv(std::max(nt, 1), 64));
-    return std::max(1, std::min(s, 64));
+    return std::max(1, std::min(s, 32));
 }
 
 int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q_stride, size_t t_stride,
@@ -23,7 +25,12 @@ int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q
     a.nq = nq;
     a.nt = nt;
     a.words = words;
-    a.splits = knn_splits(nq, nt, npairs);
+    // tuning hooks for tools/bench_knn.py: queries per lane (1 measured best) and split count
+    static const int env_q = getenv("VO_KNN_Q") ? atoi(getenv("VO_KNN_Q")) : 0;
+    static const int env_s = getenv("VO_KNN_SPLITS") ? atoi(getenv("VO_KNN_SPLITS")) : 0;
+    a.qpl = env_q == 2 || (env_q == 4 && words == 8) ? env_q : 1;
+    a.splits = knn_splits(nq, nt, npairs, a.qpl);
+    if (env_s) a.splits = std::max(1, std::min(env_s, cdiv(std::max(nt, 1), 64)));
     a.nq_cap = nq_cap;
     a.npairs = npairs;
     VO_TRY(vo_ensure(c, c->d_part, (size_t)npairs * a.splits * nq_cap * sizeof(uint2)));
