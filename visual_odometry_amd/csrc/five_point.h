@@ -29,6 +29,12 @@
 #define VO_RCP(x) (1.0 / (x))
 #endif
 
+// phase timing hook for tools/micro/solve_time.hip; compiles to nothing in the library
+#ifndef FP_TICK
+#define FP_TICK(i)
+#define FP_COUNT(i)
+#endif
+
 namespace fp_detail {
 
 VO_HD void mul_ll_acc(const double* a, const double* b, double* q, double sgn) {
@@ -61,8 +67,8 @@ VO_HD void horner(const double (&a)[D + 1], double x, double& f, double& df) {
     df = 0;
 #pragma unroll
     for (int i = D - 1; i >= 0; i--) {
-        df = df * x + f;
-        f = f * x + a[i];
+        df = fma(df, x, f);
+        f = fma(f, x, a[i]);
     }
 }
 
@@ -79,6 +85,7 @@ VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double
         xl = hi;
         xh = lo;
     }
+    FP_COUNT(2);
     double rts = 0.5 * (lo + hi);
     double dxold = fabs(hi - lo), dx = dxold, f, df;
     horner<D>(a, rts, f, df);
@@ -96,6 +103,7 @@ VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double
             if (temp == rts) break;
         }
         if (fabs(dx) <= tol * fabs(rts)) break;
+        FP_COUNT(0);
         horner<D>(a, rts, f, df);
         if (f < 0) xl = rts;
         else xh = rts;
@@ -103,26 +111,60 @@ VO_HD double bracket_root(const double (&a)[D + 1], double lo, double hi, double
     return rts;
 }
 
+// Outward search from x0 (value f0) in direction dir (-1 / +1) for a point where the sign of the
+// degree-D polynomial differs from that of f0: the step doubles, so the bracket it returns is about
+// as wide as its distance from x0 and Newton converges in a few steps.  (Starting Newton at the
+// far end of [-bound, bound] instead costs ~D ln(bound) steps per outer root: the iterate only
+// shrinks by (1 - 1/D) per step while it is far from all roots.)  Returns false if |x| passes
+// `bound` (a root bound of c and hence of all its derivatives) without a sign change.
+template <int D>
+VO_HD bool outward_bracket(const double (&a)[D + 1], double x0, double f0, double dir, double bound,
+                           double& xin, double& xout, double& fout) {
+    double step = 0.25 * fmax(fabs(x0), 0.01);
+    xin = x0;
+    for (;;) {
+        xout = xin + dir * step;
+        double d;
+        FP_COUNT(1);
+        horner<D>(a, xout, fout, d);
+        if ((fout < 0) != (f0 < 0)) return true;
+        if (!(fabs(xout) <= bound)) return false;
+        xin = xout;
+        step *= 2;
+    }
+}
+
 // Real roots of the (10-D)-th derivative of c (degree D), bracketed by the roots of the next
-// derivative, which are S(prev..prev+nprev) in ascending order.  Writes S(cur..), returns count.
+// derivative, which are S(prev..prev+nprev) in ascending order (with none, 0 splits the line).
+// The outer intervals have no far end: the sign at infinity is that of the leading coefficient.
+// Writes S(cur..), returns count.
 template <int D, class S>
 VO_HD int level_roots(const double (&c)[11], double bound, int nprev, const S& s, int prev, int cur) {
     double a[D + 1];
 #pragma unroll
     for (int i = 0; i <= D; i++) a[i] = c[i + (10 - D)] * falling(i + (10 - D), 10 - D);
+    const double tol = D == 10 ? 4e-16 : 1e-9;
+    const bool neg_at_minf = (D & 1) ? (a[D] > 0) : (a[D] < 0), neg_at_pinf = a[D] < 0;
     int ncur = 0;
-    double lo = -bound, flo, d;
+    double lo = nprev > 0 ? s(prev) : 0.0, flo, d;
     horner<D>(a, lo, flo, d);
-    for (int j = 0; j <= nprev; j++) {
-        const double hi = j < nprev ? s(prev + j) : bound;
+    if ((flo < 0) != neg_at_minf) {
+        double xin, xout, fout;
+        if (outward_bracket<D>(a, lo, flo, -1.0, bound, xin, xout, fout))
+            s(cur + ncur++) = bracket_root<D>(a, xout, xin, fout, tol);
+    }
+    for (int j = 1; j < nprev; j++) {
+        const double hi = s(prev + j);
         double fhi;
         horner<D>(a, hi, fhi, d);
-        if ((flo < 0) != (fhi < 0)) {
-            s(cur + ncur) = bracket_root<D>(a, lo, hi, flo, D == 10 ? 4e-16 : 1e-9);
-            ncur++;
-        }
+        if ((flo < 0) != (fhi < 0)) s(cur + ncur++) = bracket_root<D>(a, lo, hi, flo, tol);
         lo = hi;
         flo = fhi;
+    }
+    if ((flo < 0) != neg_at_pinf) {
+        double xin, xout, fout;
+        if (outward_bracket<D>(a, lo, flo, 1.0, bound, xin, xout, fout))
+            s(cur + ncur++) = bracket_root<D>(a, xin, xout, flo, tol);
     }
     return ncur;
 }
@@ -224,6 +266,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
             for (int k = 0; k < 9; k++) s(200 + 9 * (i - 5) + k) = basis[i][k];
         }
     }
+    FP_TICK(1);
     // ---- ten cubic constraints -> 10x20 matrix in S (row r at 20 r) -----------------------------
     {
         double e[9][4];  // entry (r,c) of E(x,y,z) = x N0 + y N1 + z N2 + N3
@@ -290,37 +333,62 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
                 for (int q = 0; q < 20; q++) s(20 * (1 + 3 * i + j) + q) = cub[q];
             }
     }
+    FP_TICK(2);
     // ---- Gauss-Jordan on the first ten columns, partial pivoting ---------------------------------
     // Only rows 4..9 of the reduced right-hand block are used afterwards, so finished rows 0..3
     // are not updated any further.
+    // Row loops have compile-time trip counts (rows that take no part are skipped by a uniform
+    // branch) so that the LDS reads of a row are issued back to back instead of one per FMA.
     for (int col = 0; col < 10; col++) {
+        double cv[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) cv[r] = s(20 * r + col);
         int piv = col;
-        double best = fabs(s(20 * col + col));
-        for (int r = col + 1; r < 10; r++) {
-            const double v = fabs(s(20 * r + col));
-            if (v > best) {
+        double best = -1.0;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const double v = fabs(cv[r]);
+            if (r >= col && v > best) {
                 best = v;
                 piv = r;
             }
         }
         if (!(best > 1e-300)) return 0;
         double prow[20];
-        const double inv = 1.0 / s(20 * piv + col);
+#pragma unroll
+        for (int k = 0; k < 20; k++) prow[k] = s(20 * piv + k);
+        if (piv != col) {
+            double crow[20];
+#pragma unroll
+            for (int k = 0; k < 20; k++) crow[k] = s(20 * col + k);
+#pragma unroll
+            for (int k = 0; k < 20; k++) s(20 * piv + k) = crow[k];
+            // the old row `col` now sits at `piv`: its entry in this column moves with it
+#pragma unroll
+            for (int r = 0; r < 10; r++)
+                if (r == piv) cv[r] = crow[col];
+        }
+        const double inv = 1.0 / prow[col];
 #pragma unroll
         for (int k = 0; k < 20; k++) {
-            const double pv = s(20 * piv + k);
-            if (piv != col) s(20 * piv + k) = s(20 * col + k);
-            prow[k] = pv * inv;
+            prow[k] *= inv;
             s(20 * col + k) = prow[k];
         }
-        for (int r = (col < 4 ? col + 1 : 4); r < 10; r++) {
-            if (r == col) continue;
-            const double f = s(20 * r + col);
 #pragma unroll
-            for (int k = 0; k < 20; k++)
-                if (k > col) s(20 * r + k) -= f * prow[k];
+        for (int r = 1; r < 10; r++) {
+            if (r > col || (r >= 4 && r < col)) {
+                const double f = cv[r];
+                double row[20];
+#pragma unroll
+                for (int k = 1; k < 20; k++)
+                    if (k >= 10 || k > col) row[k] = s(20 * r + k);
+#pragma unroll
+                for (int k = 1; k < 20; k++)
+                    if (k >= 10 || k > col) s(20 * r + k) = row[k] - f * prow[k];
+            }
         }
     }
+    FP_TICK(3);
     // ---- B(z): rows e - z f, g - z h, i - z j; coefficients lowest degree first ------------------
     double c[11];
     {
@@ -377,6 +445,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
                 for (int q = 0; q <= DEG[CA[t]] + DEG[CB[t]]; q++) c[p + q] += sg * (B[0][t][p] * m[q]);
         }
     }
+    FP_TICK(4);
     // ---- real roots of c ---------------------------------------------------------------------
     int nroots;
     {
@@ -404,6 +473,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
         n = level_roots<9>(c, bound, n, s, 10, 0);
         nroots = level_roots<10>(c, bound, n, s, 0, 10);  // roots at S(10..)
     }
+    FP_TICK(5);
     // ---- back-substitution ---------------------------------------------------------------------
     int count = 0;
     for (int i = 0; i < nroots; i++) {
