@@ -84,6 +84,7 @@ struct vo_ctx {
     float geom_scale = 0;
     std::vector<uint32_t> coef_host;
     std::vector<size_t> coef_x, coef_y;  // per level offsets into d_coef (uint32 units)
+    std::vector<int> coef_ldw, coef_rows;  // per level LDS tile of the resize kernel (dwords per row, rows)
 
     // ---- matcher workspace ---------------------------------------------------------------
     DevBuf d_q, d_t;    // descriptor uploads (host-pointer entry points)

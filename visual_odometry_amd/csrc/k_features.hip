@@ -50,37 +50,59 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Pyramid level l from level l-1: cv::resize(INTER_LINEAR_EXACT), 8.8 fixed-point coefficients
-// from host tables (xtab/ytab entries: ofs << 16 | c1, c0 = 256 - c1).  The reflect-101 frame of
-// the new level is produced by evaluating the resize at the reflected coordinate.
+// from host tables (entries: ofs << 16 | c1, c0 = 256 - c1).  The tables are padded and already
+// reflected: xtab[i] belongs to x = i - 4, ytab[i] to y = i - 3, so the reflect-101 frame of the
+// new level is produced by the same code as its interior.  A block makes 256 x PR_ROWS pixels: the
+// source rectangle they read (known from the tables, which are monotone in the reflected
+// coordinate) is staged in LDS with aligned dword loads, then every thread makes four pixels of two
+// rows from LDS bytes and stores aligned dwords.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_resize(const PyrGeom* __restrict__ g, uint8_t* __restrict__ pyr,
                                                     int level, const uint32_t* __restrict__ xtab,
-                                                    const uint32_t* __restrict__ ytab) {
-    const int f = blockIdx.z;
+                                                    const uint32_t* __restrict__ ytab, int ldw) {
+    extern __shared__ uint32_t rs_tile[];
+    const int f = blockIdx.z, tid = threadIdx.x;
     const int dw = g->lv[level].w, dh = g->lv[level].h, dpitch = g->lv[level].pitch;
-    const int x4 = -4 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = -3 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x4 >= dw + 3 || y >= dh + 3) return;
     const int sw = g->lv[level - 1].w, sh = g->lv[level - 1].h, spitch = g->lv[level - 1].pitch;
+    const int xa = -4 + 256 * (int)blockIdx.x, ya = -3 + PR_ROWS * (int)blockIdx.y;
+    int lo, hi;
+    vo_reflect_range(xa, min(xa + 255, dw + 2), dw, lo, hi);
+    const int sx0 = (int)(xtab[lo + 4] >> 16) & ~3, sx1 = min((int)(xtab[hi + 4] >> 16) + 1, sw - 1);
+    vo_reflect_range(ya, min(ya + PR_ROWS - 1, dh + 2), dh, lo, hi);
+    const int sy0 = (int)(ytab[lo + 3] >> 16), sy1 = min((int)(ytab[hi + 3] >> 16) + 1, sh - 1);
+    const int ndw = (sx1 - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= ldw, <= the rows the launch sized LDS for
     const uint8_t* s = level_px((const uint8_t*)pyr, g, f, level - 1);
-    const uint32_t ty = ytab[reflect101(y, dh)];
-    const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
-    const int oy1 = min(oy + 1, sh - 1);
-    const uint8_t* r0 = s + (size_t)oy * spitch;
-    const uint8_t* r1 = s + (size_t)oy1 * spitch;
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t tx = xtab[reflect101(x4 + j, dw)];
-        const int ox = tx >> 16, cx1 = tx & 0xffff, cx0 = 256 - cx1;
-        const int ox1 = min(ox + 1, sw - 1);
-        const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-        const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
-        const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
-        out |= min(v, 255u) << (8 * j);
+    for (int i = tid; i < nrows * ndw; i += 256) {
+        const int r = i / ndw, c = i - r * ndw;
+        rs_tile[r * ldw + c] = *reinterpret_cast<const uint32_t*>(s + (ptrdiff_t)(sy0 + r) * spitch + sx0 + 4 * c);
     }
+    __syncthreads();
+    const int x4 = xa + 4 * (tid & 63);
+    if (x4 >= dw + 3) return;
+    const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + x4 + 4);
+    const uint32_t tx[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(rs_tile) - sx0;
     uint8_t* dst = level_px(pyr, g, f, level);
-    *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
+    for (int k = tid >> 6; k < PR_ROWS; k += 4) {
+        const int y = ya + k;
+        if (y >= dh + 3) break;
+        const uint32_t ty = ytab[y + 3];
+        const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
+        const int oy1 = min(oy + 1, sh - 1);
+        const uint8_t* r0 = t8 + (oy - sy0) * ldw * 4;
+        const uint8_t* r1 = t8 + (oy1 - sy0) * ldw * 4;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ox = tx[j] >> 16, cx1 = tx[j] & 0xffff, cx0 = 256 - cx1;
+            const int ox1 = min(ox + 1, sw - 1);
+            const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
+            const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+            const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
+            out |= min(v, 255u) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,60 +771,80 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
 // ---------------------------------------------------------------------------------------------
 // GaussianBlur 7x7 sigma 2 (cv's 8-bit fixed-point separable path, BORDER_REFLECT_101): row pass
 // in 32-bit ints, column pass (sum + 2^15) >> 16, saturate.  No LDS: a thread owns a column of four
-// pixels, reads three aligned dwords per input row (the reflect-101 frame is real memory) and
-// keeps the last seven row sums in registers while it walks down GB_ROWS output rows.
+// pixels, reads three aligned dwords per input row (the reflect-101 frame is real memory) and walks
+// down GB_ROWS output rows two input rows at a time.  All levels of all frames are one launch
+// (GaussGrid maps blockIdx.x to a level).  The taps (<= 55) are bytes and the row sums
+// (<= 257 * 255 = 65535) are 16-bit, so the row pass is two v_dot4_u32_u8 per pixel on byte windows
+// cut with v_alignbyte, and the column pass four v_dot2_u32_u16 per pixel on row sums packed in
+// (even row, odd row) pairs: the sums are exact integers either way, the same as cv's.
 // ---------------------------------------------------------------------------------------------
 #define GB_ROWS 16
+typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, a), __builtin_bit_cast(vo_u16x2, b), c, false);
+}
+
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
-                                                uint8_t* __restrict__ blur, Taps7 taps, int level) {
-    const int f = blockIdx.z;
+                                                uint8_t* __restrict__ blur, Taps7 taps, GaussGrid gg) {
+    const int f = blockIdx.y;
+    int level = 0;
+    for (int i = 1; i < gg.nlevels; i++)
+        if ((int)blockIdx.x >= gg.b0[i]) level = i;
+    const int local = blockIdx.x - gg.b0[level];
+    const int bxi = local % gg.bx[level], byi = local / gg.bx[level];
     const int w = g->lv[level].w, h = g->lv[level].h, pitch = g->lv[level].pitch;
-    const int x4 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y0 = GB_ROWS * (blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int x4 = 4 * (bxi * 64 + (threadIdx.x & 63));
+    const int y0 = GB_ROWS * (byi * 4 + (threadIdx.x >> 6));
     if (x4 >= w || y0 >= h) return;
     const uint8_t* src = level_px(pyr, g, f, level) + x4;
     uint8_t* dst = level_px(blur, g, f, level) + x4;
-    // all quantities are non-negative and below 2^24: 24-bit multiplies (full rate), unsigned math
-    uint32_t t[7];
-#pragma unroll
-    for (int k = 0; k < 7; k++) t[k] = (uint32_t)taps.t[k];
-    uint32_t H[7][4] = {};
-#pragma unroll
-    for (int r = 0; r < GB_ROWS + 6; r++) {
+    const uint32_t t0 = taps.t[0], t1 = taps.t[1], t2 = taps.t[2], t3 = taps.t[3], t4 = taps.t[4], t5 = taps.t[5],
+                   t6 = taps.t[6];
+    const uint32_t TA = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24), TB = t4 | (t5 << 8) | (t6 << 16);
+    // column taps for an even output row (input rows 2m .. 2m+6) and an odd one (2m+1 .. 2m+7)
+    const uint32_t E0 = t0 | (t1 << 16), E1 = t2 | (t3 << 16), E2 = t4 | (t5 << 16), E3 = t6;
+    const uint32_t O0 = t0 << 16, O1 = t1 | (t2 << 16), O2 = t3 | (t4 << 16), O3 = t5 | (t6 << 16);
+    auto row_sums = [&](int r, uint32_t (&H)[4]) {
         const int y = min(y0 - 3 + r, h + 2);
         const uint32_t* row = reinterpret_cast<const uint32_t*>(src + (ptrdiff_t)y * pitch);
         const uint32_t A = row[-1], B = row[0], C = row[1];
-        uint32_t b[12];
+        // pixel j sums bytes 1+j .. 7+j of the 12-byte window A B C
+        H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), TA,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), TB, 0, false), false);
+        H[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), TA,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), TB, 0, false), false);
+        H[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), TA,
+                                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), TB, 0, false), false);
+        H[3] = __builtin_amdgcn_udot4(B, TA, __builtin_amdgcn_udot4(C, TB, 0, false), false);
+    };
+    uint32_t P[4][4] = {};  // the last four (even, odd) pairs of row sums, per pixel
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            b[k] = (A >> (8 * k)) & 0xffu;
-            b[4 + k] = (B >> (8 * k)) & 0xffu;
-            b[8 + k] = (C >> (8 * k)) & 0xffu;
-        }
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) H[q][j] = H[q + 1][j];
+    for (int k = 0; k < (GB_ROWS + 6) / 2; k++) {
+        uint32_t He[4], Ho[4];
+        row_sums(2 * k, He);
+        row_sums(2 * k + 1, Ho);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; k++) acc += __umul24(t[k], b[1 + j + k]);
-            H[6][j] = acc;
+            P[0][j] = P[1][j];
+            P[1][j] = P[2][j];
+            P[2][j] = P[3][j];
+            P[3][j] = He[j] | (Ho[j] << 16);
         }
-        if (r >= 6) {
-            const int yo = y0 + r - 6;
-            if (yo < h) {
-                uint32_t o = 0;
+        if (k >= 3) {
+            const int yo = y0 + 2 * (k - 3);
+            uint32_t oe = 0, oo = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint32_t acc = 1u << 15;
-#pragma unroll
-                    for (int q = 0; q < 7; q++) acc += __umul24(t[q], H[q][j]);
-                    o |= min(acc >> 16, 255u) << (8 * j);
-                }
-                *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)yo * pitch) = o;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t ae =
+                    udot2(P[0][j], E0, udot2(P[1][j], E1, udot2(P[2][j], E2, udot2(P[3][j], E3, 1u << 15))));
+                const uint32_t ao =
+                    udot2(P[0][j], O0, udot2(P[1][j], O1, udot2(P[2][j], O2, udot2(P[3][j], O3, 1u << 15))));
+                oe |= min(ae >> 16, 255u) << (8 * j);
+                oo |= min(ao >> 16, 255u) << (8 * j);
             }
+            if (yo < h) *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)yo * pitch) = oe;
+            if (yo + 1 < h) *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)(yo + 1) * pitch) = oo;
         }
     }
 }
@@ -861,9 +903,10 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
 }
 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
-                       const uint32_t* xtab, const uint32_t* ytab, int nframes) {
-    dim3 grid(cdiv(cdiv(hg.lv[level].w + 7, 4), 64), cdiv(hg.lv[level].h + 6, 4), nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, d_geom, pyr, level, xtab, ytab);
+                       const uint32_t* xtab, const uint32_t* ytab, int ldw, int lrows, int nframes) {
+    dim3 grid(cdiv(hg.lv[level].w + 7, 256), cdiv(hg.lv[level].h + 6, PR_ROWS), nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * lrows * 4, st, d_geom, pyr, level, xtab, ytab,
+                       ldw);
 }
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
@@ -912,10 +955,16 @@ void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, 
 
 void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
                    const Taps7& taps, int nlevels_used, int nframes) {
-    for (int l = 0; l < nlevels_used && l < hg.nlevels; l++) {
-        dim3 grid(cdiv(cdiv(hg.lv[l].w, 4), 64), cdiv(cdiv(hg.lv[l].h, GB_ROWS), 4), nframes);
-        hipLaunchKernelGGL(k_gauss7, grid, dim3(256), 0, st, pyr, d_geom, blur, taps, l);
+    GaussGrid gg;
+    gg.nlevels = std::min(nlevels_used, hg.nlevels);
+    int b = 0;
+    for (int l = 0; l < gg.nlevels; l++) {
+        gg.b0[l] = b;
+        gg.bx[l] = cdiv(cdiv(hg.lv[l].w, 4), 64);
+        b += gg.bx[l] * cdiv(cdiv(hg.lv[l].h, GB_ROWS), 4);
     }
+    if (b == 0) return;
+    hipLaunchKernelGGL(k_gauss7, dim3(b, nframes), dim3(256), 0, st, pyr, d_geom, blur, taps, gg);
 }
 
 void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,

@@ -37,8 +37,33 @@ struct PyrGeom {
     LevelGeom lv[VO_ORB_MAX_LEVELS];
 };
 
+// Range [lo, hi] of reflect-101 coordinates that the destination coordinates a..b (a <= b, a >= -n + 1,
+// b <= 2n - 2) of an axis of length n map to.
+static inline __host__ __device__ void vo_reflect_range(int a, int b, int n, int& lo, int& hi) {
+    lo = a;
+    hi = b;
+    if (a < 0) {
+        lo = b >= 0 ? 0 : -b;
+        hi = hi > -a ? hi : -a;
+    }
+    if (b >= n) {
+        const int r = 2 * n - 2 - b;
+        lo = lo < r ? lo : r;
+        hi = n - 1;
+    }
+    lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
+    hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
+}
+#define PR_ROWS 8  // destination rows per block of the pyramid resize
+
 struct Taps7 {
     int t[7];
+};
+// blocks of the blur launch: level l owns blocks [b0[l], b0[l+1]), bx[l] of them per block row
+struct GaussGrid {
+    int nlevels;
+    int b0[VO_ORB_MAX_LEVELS];
+    int bx[VO_ORB_MAX_LEVELS];
 };
 
 // candidate corner / selected keypoint in level coordinates (16 bytes)
@@ -64,7 +89,7 @@ struct Quotas {
 void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, int stride, const PyrGeom* d_geom,
                        const PyrGeom& hg, uint8_t* pyr, int nframes);
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
-                       const uint32_t* xtab, const uint32_t* ytab, int nframes);
+                       const uint32_t* xtab, const uint32_t* ytab, int ldw, int lrows, int nframes);
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
                      unsigned long long* masks, int threshold, int border, int nms, int nframes);
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,

@@ -134,17 +134,47 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
         g.segs_total = seg;
         g.rows_total = row;
         g.pyr_bytes = off;
-        // coefficient tables for levels >= 1
+        // coefficient tables for levels >= 1, padded by the reflect-101 frame the resize kernel also
+        // writes (x = -4 .. w + 7, y = -3 .. h + 2), 16-byte aligned; and the LDS tile that holds the
+        // source rectangle of any 256 x PR_ROWS block of the level
         c->coef_host.clear();
         c->coef_x.assign(nlevels, 0);
         c->coef_y.assign(nlevels, 0);
+        c->coef_ldw.assign(nlevels, 0);
+        c->coef_rows.assign(nlevels, 0);
+        auto reflect = [](int i, int n) {
+            while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+            return i;
+        };
+        auto padded_table = [&](int ssize, int dsize, int before, int after) {
+            std::vector<uint32_t> raw(dsize);
+            linear_table(ssize, dsize, raw.data());
+            const size_t at = c->coef_host.size();
+            for (int i = -before; i < dsize + after; i++) c->coef_host.push_back(raw[reflect(i, dsize)]);
+            while (c->coef_host.size() % 4) c->coef_host.push_back(0);
+            return at;
+        };
         for (int l = 1; l < nlevels; l++) {
-            c->coef_x[l] = c->coef_host.size();
-            c->coef_host.resize(c->coef_host.size() + g.lv[l].w);
-            linear_table(g.lv[l - 1].w, g.lv[l].w, &c->coef_host[c->coef_x[l]]);
-            c->coef_y[l] = c->coef_host.size();
-            c->coef_host.resize(c->coef_host.size() + g.lv[l].h);
-            linear_table(g.lv[l - 1].h, g.lv[l].h, &c->coef_host[c->coef_y[l]]);
+            const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+            c->coef_x[l] = padded_table(sw, dw, 4, 8);
+            c->coef_y[l] = padded_table(sh, dh, 3, 3);
+            const uint32_t* xt = &c->coef_host[c->coef_x[l]];
+            const uint32_t* yt = &c->coef_host[c->coef_y[l]];
+            int ldw = 1, rows = 1, lo, hi;
+            for (int xa = -4; xa < dw + 3; xa += 256) {
+                vo_reflect_range(xa, std::min(xa + 255, dw + 2), dw, lo, hi);
+                const int sx0 = (int)(xt[lo + 4] >> 16) & ~3, sx1 = std::min((int)(xt[hi + 4] >> 16) + 1, sw - 1);
+                ldw = std::max(ldw, (sx1 - sx0) / 4 + 1);
+            }
+            for (int ya = -3; ya < dh + 3; ya += PR_ROWS) {
+                vo_reflect_range(ya, std::min(ya + PR_ROWS - 1, dh + 2), dh, lo, hi);
+                const int sy0 = (int)(yt[lo + 3] >> 16), sy1 = std::min((int)(yt[hi + 3] >> 16) + 1, sh - 1);
+                rows = std::max(rows, sy1 - sy0 + 1);
+            }
+            if ((size_t)ldw * rows * 4 > 64 * 1024)
+                return c->fail(VO_ERR_INVALID, "scale factor %g is too large for the resize tile", (double)sf);
+            c->coef_ldw[l] = ldw;
+            c->coef_rows[l] = rows;
         }
         VO_HIP(c, hipStreamSynchronize(c->stream));
         VO_TRY(vo_ensure(c, c->d_geom, sizeof(PyrGeom)));
@@ -210,7 +240,7 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
     launch_pyr_level0(st, d_img, frame_stride, stride, dg, g, pyr, nframes);
     for (int l = 1; l < g.nlevels; l++)
         launch_pyr_resize(st, dg, g, pyr, l, c->d_coef.as<uint32_t>() + c->coef_x[l],
-                          c->d_coef.as<uint32_t>() + c->coef_y[l], nframes);
+                          c->d_coef.as<uint32_t>() + c->coef_y[l], c->coef_ldw[l], c->coef_rows[l], nframes);
     {
         ProfScope ps(c, VO_PROF_FAST);
         launch_fast_nms(st, dg, g, pyr, c->d_score.as<uint8_t>(), c->d_masks.as<unsigned long long>(),
@@ -490,7 +520,8 @@ int vo_orb_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, con
                       c->d_pyr.as<uint8_t>(), 1);
     for (int l = 1; l < c->geom.nlevels; l++)
         launch_pyr_resize(c->stream, c->d_geom.as<PyrGeom>(), c->geom, c->d_pyr.as<uint8_t>(), l,
-                          c->d_coef.as<uint32_t>() + c->coef_x[l], c->d_coef.as<uint32_t>() + c->coef_y[l], 1);
+                          c->d_coef.as<uint32_t>() + c->coef_x[l], c->d_coef.as<uint32_t>() + c->coef_y[l],
+                          c->coef_ldw[l], c->coef_rows[l], 1);
     int* nkp = c->h_nkp.as<int>();
     nkp[0] = cnt;
     nkp[1] = 0;
