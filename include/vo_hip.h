@@ -64,6 +64,22 @@ int vo_orb_detect_compute(vo_ctx* ctx, const uint8_t* gray, int w, int h, int st
 int vo_orb_compute(vo_ctx* ctx, const uint8_t* gray, int w, int h, int stride,
                    const vo_orb_params* p, vo_keypoint* kp_inout, int* n_inout, uint8_t* desc);
 
+/* ---- tracker: replaces FeatureTracker (src/features/feature_tracker.cpp) ------------------ */
+
+void vo_lk_params_default(vo_lk_params* p);
+
+/* optical_flow_->calc(vo0->image, vo1->image, vo0->points, vo1->points, status) with
+ * cv::SparsePyrLKOpticalFlow::create() (21x21 window, 4 levels, 30 iterations / eps 0.01,
+ * minEigThreshold 1e-4, no initial flow)
+ * reference: src/features/feature_tracker.cpp:6,13 (cuda variant src/features/cuda/feature_tracker.cpp:5,18).
+ * prev / next: gray planes of w x h; prev_pts / next_pts: n x 2 floats; status: n bytes of 0/1.
+ * The pyramid of `next` stays in the context: a following call with prev == NULL and the same
+ * geometry tracks from that image (the per-image loop tracks frame k -> k+1, then k+1 -> k+2,
+ * src/visual_odometry/visual_odometry.cpp:39).  removePoints() (src/features/utils.h:9-58) is
+ * host bookkeeping and lives in the host mirror. */
+int vo_lk_track(vo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+                const float* prev_pts, int n, const vo_lk_params* params, float* next_pts, uint8_t* status);
+
 /* ---- matcher: replaces the body of matcher() (src/matcher/matcher.cpp) ------------------- */
 
 /* matcher->knnMatch(desc_q, desc_t, matches, 2) with "BruteForce-Hamming"
@@ -199,6 +215,14 @@ int vo_ctx_get_option(vo_ctx* ctx, int option, int* value);
 #define VO_DBG_BLUR 1
 int vo_debug_read_level(vo_ctx* ctx, int which, int frame, int level, uint8_t* out, int cap, int* w, int* h);
 int vo_prof_get(vo_ctx* ctx, int which, int reset, int* launches, double* total_ms);
+
+/* Test hook (no reference counterpart): level `level` of the last vo_lk_track call's pyramids
+ * (VO_DBG_LK_PREV / VO_DBG_LK_NEXT: cv::pyrDown chain, w x h bytes) or of the Scharr derivative
+ * image of prev (VO_DBG_LK_DERIV: w x h x 2 int16, dx dy interleaved), tightly packed; cap in bytes. */
+#define VO_DBG_LK_PREV 0
+#define VO_DBG_LK_NEXT 1
+#define VO_DBG_LK_DERIV 2
+int vo_debug_read_lk_level(vo_ctx* ctx, int which, int level, void* out, int cap, int* w, int* h);
 
 #ifdef __cplusplus
 }

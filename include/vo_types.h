@@ -46,6 +46,21 @@ typedef struct vo_orb_params {
     int32_t fast_threshold;/* 20 */
 } vo_orb_params;
 
+/* cv::SparsePyrLKOpticalFlow::create(...) arguments. The reference takes every default
+ * (src/features/feature_tracker.cpp:6, cuda variant src/features/cuda/feature_tracker.cpp:5);
+ * vo_lk_params_default fills them in. flags are fixed at 0 (no initial flow, no eigenvalue output). */
+typedef struct vo_lk_params {
+    int32_t win_w, win_h;      /* 21 x 21 (3 .. 32 supported) */
+    int32_t max_level;         /* 3 */
+    int32_t max_count;         /* 30 (TermCriteria COUNT) */
+    double epsilon;            /* 0.01 (TermCriteria EPS) */
+    double min_eig_threshold;  /* 1e-4 */
+    int32_t channels;          /* 3: the image is the 8UC3 that cv::imread makes of a gray PNG (what the
+                                  reference's CPU build tracks on, src/main.cpp:61) given as its single
+                                  gray plane; 1: a true single-channel image (the cuda variant's gpu_image) */
+    int32_t reserved;
+} vo_lk_params;
+
 /* cv method enum values used by findEssentialMat (reference: src/matcher/matcher.cpp:42 RANSAC,
  * src/visual_odometry/vo_pose.h:14 LMEDS). */
 #define VO_LMEDS 4

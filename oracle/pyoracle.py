@@ -29,6 +29,19 @@ class OrbParams(C.Structure):
                 ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
 
 
+class LkParams(C.Structure):
+    _fields_ = [("win_w", C.c_int32), ("win_h", C.c_int32), ("max_level", C.c_int32), ("max_count", C.c_int32),
+                ("epsilon", C.c_double), ("min_eig_threshold", C.c_double), ("channels", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def lk_params(**kw):
+    p = LkParams(21, 21, 3, 30, 0.01, 1e-4, 3, 0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 def orb_params(nfeatures=2000, **kw):
     p = OrbParams(nfeatures, 1.2, 8, 31, 0, 2, 0, 31, 20)
     for k, v in kw.items():
@@ -279,3 +292,51 @@ def projection_matrix(K, pose):
     P = np.zeros((3, 4))
     lib().vo_oracle_projection_matrix(_p(K), _p(pose), _p(P))
     return P
+
+
+# ---- tracker -------------------------------------------------------------------------------
+def lk_levels(w, h, params):
+    lw = (C.c_int * 16)()
+    lh = (C.c_int * 16)()
+    n = lib().vo_oracle_lk_levels(int(w), int(h), C.byref(params), lw, lh)
+    return [(lw[i], lh[i]) for i in range(n)]
+
+
+def lk_level(gray, params, level):
+    """(image, deriv) of one tracker pyramid level; deriv is h x w x 2 int16 (dx, dy)."""
+    gray = _img(gray)
+    h, w = gray.shape
+    lw, lh = lk_levels(w, h, params)[level]
+    img = np.zeros((lh, lw), np.uint8)
+    der = np.zeros((lh, lw, 2), np.int16)
+    rc = lib().vo_oracle_lk_level(_p(gray), w, h, w, C.byref(params), int(level), _p(img), _p(der))
+    assert rc == 0, rc
+    return img, der
+
+
+def lk_track(prev, nxt, prev_pts, params):
+    prev, nxt = _img(prev), _img(nxt)
+    h, w = prev.shape
+    assert nxt.shape == prev.shape
+    p0 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    n = len(p0)
+    p1 = np.zeros((max(n, 1), 2), np.float32)
+    st = np.zeros(max(n, 1), np.uint8)
+    rc = lib().vo_oracle_lk_track(_p(prev), _p(nxt), w, h, w, _p(p0), n, C.byref(params), _p(p1), _p(st))
+    assert rc == 0, rc
+    return p1[:n].copy(), st[:n].copy()
+
+
+def remove_points(p0, p1, status, pts3d=None, mask=None):
+    """removePoints(): returns (p0, p1, status, pts3d, mask, ret)."""
+    p0 = np.array(p0, dtype=np.float32, copy=True).reshape(-1, 2)
+    p1 = np.array(p1, dtype=np.float32, copy=True).reshape(-1, 2)
+    st = np.array(status, dtype=np.uint8, copy=True)
+    n = len(p0)
+    p3 = np.array(pts3d if pts3d is not None else np.zeros((0, 3)), dtype=np.float64, copy=True).reshape(-1, 3)
+    mk = np.array(mask if mask is not None else np.zeros(0), dtype=np.uint8, copy=True).reshape(-1)
+    n_out, n3, nm, ret = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().vo_oracle_remove_points(_p(p0), _p(p1), n, _p(st), _p(p3), len(p3), _p(mk), len(mk), C.byref(n_out),
+                                       C.byref(n3), C.byref(nm), C.byref(ret))
+    assert rc == 0, rc
+    return p0[: n_out.value].copy(), p1[: n_out.value].copy(), st, p3[: n3.value].copy(), mk[: nm.value].copy(), ret.value

@@ -63,6 +63,29 @@ int vo_oracle_orb_detect_compute(const uint8_t* gray, int w, int h, int stride,
 int vo_oracle_orb_compute(const uint8_t* gray, int w, int h, int stride, const vo_orb_params* p,
                           vo_keypoint* kp_inout, int* n_inout, uint8_t* desc);
 
+/* ---- tracker -------------------------------------------------------------------------- */
+
+void vo_oracle_lk_params_default(vo_lk_params* p);
+
+/* Level sizes of buildOpticalFlowPyramid; returns the number of levels actually used. */
+int vo_oracle_lk_levels(int w, int h, const vo_lk_params* prm, int* lw, int* lh);
+
+/* One level of the tracker's pyramid (pyrDown chain) and its Scharr derivative image
+ * (dx, dy interleaved), tight; either output may be NULL. */
+int vo_oracle_lk_level(const uint8_t* img, int w, int h, int stride, const vo_lk_params* prm, int level,
+                       uint8_t* out_img, int16_t* out_deriv);
+
+/* optical_flow_->calc(prev, next, prev_pts, next_pts, status)
+ * reference: src/features/feature_tracker.cpp:13. Images are gray planes (see vo_lk_params.channels). */
+int vo_oracle_lk_track(const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts,
+                       int n, const vo_lk_params* prm, float* next_pts, uint8_t* status);
+
+/* removePoints(vo0, vo1, &status); reference: src/features/utils.h:9-58. Compacts p0, p1 (n x 2),
+ * pts3d (n3d x 3) and mask (nmask) in place, clears status of points with negative coordinates,
+ * *ret = the function's return value. */
+int vo_oracle_remove_points(float* p0, float* p1, int n, uint8_t* status, double* pts3d, int n3d, uint8_t* mask,
+                            int nmask, int* n_out, int* n3d_out, int* nmask_out, int* ret);
+
 /* ---- matcher -------------------------------------------------------------------------- */
 
 /* BFMatcher(NORM_HAMMING).knnMatch(q, t, matches, 2); reference: src/matcher/matcher.cpp:10,17.

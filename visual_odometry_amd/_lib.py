@@ -18,6 +18,7 @@ SYMBOLS = [
     "vo_knn2_hamming", "vo_match_filter", "vo_find_essential", "vo_recover_pose", "vo_triangulate",
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
     "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
+    "vo_lk_params_default", "vo_lk_track", "vo_debug_read_lk_level",
     "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_get_stats",
 ]
 
@@ -26,6 +27,12 @@ class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
                 ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32)]
+
+
+class LkParams(C.Structure):
+    _fields_ = [("win_w", C.c_int32), ("win_h", C.c_int32), ("max_level", C.c_int32), ("max_count", C.c_int32),
+                ("epsilon", C.c_double), ("min_eig_threshold", C.c_double), ("channels", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class Limits(C.Structure):

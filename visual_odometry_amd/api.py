@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import OrbParams, Limits, PairParams, PairResult
+from ._lib import OrbParams, Limits, PairParams, PairResult, LkParams
 
 KP_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -30,6 +30,14 @@ class VoError(RuntimeError):
 def orb_params(nfeatures=2000, **kw):
     p = OrbParams()
     _lib.lib().vo_orb_params_default(C.byref(p), int(nfeatures))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def lk_params(**kw):
+    p = LkParams()
+    _lib.lib().vo_lk_params_default(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -87,6 +95,33 @@ class VoContext:
 
     def synchronize(self):
         self._check(self.L.vo_ctx_synchronize(self.h))
+
+    # ---- tracker -----------------------------------------------------------------------
+    def lk_track(self, prev, nxt, prev_pts, params):
+        """prev may be None: track from the previous call's `nxt` image (its pyramid is cached)."""
+        nxt = _img(nxt)
+        h, w = nxt.shape
+        stride = nxt.strides[0]
+        if prev is not None:
+            prev = _img(prev)
+            assert prev.shape == nxt.shape and prev.strides[0] == stride
+        p0 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+        n = len(p0)
+        p1 = np.zeros((max(n, 1), 2), np.float32)
+        st = np.zeros(max(n, 1), np.uint8)
+        self._check(self.L.vo_lk_track(self.h, _p(prev), _p(nxt), w, h, stride, _p(p0), n, C.byref(params), _p(p1),
+                                       _p(st)))
+        return p1[:n].copy(), st[:n].copy()
+
+    def debug_read_lk_level(self, which, level):
+        """which: 0 prev pyramid, 1 next pyramid, 2 derivative image (h x w x 2 int16)."""
+        w, h = C.c_int(0), C.c_int(0)
+        cap = self.limits.max_width * self.limits.max_height * 4
+        buf = np.zeros(cap, np.uint8)
+        self._check(self.L.vo_debug_read_lk_level(self.h, int(which), int(level), _p(buf), cap, C.byref(w), C.byref(h)))
+        if which == 2:
+            return buf[: w.value * h.value * 4].view(np.int16).reshape(h.value, w.value, 2).copy()
+        return buf[: w.value * h.value].reshape(h.value, w.value).copy()
 
     # ---- features ----------------------------------------------------------------------
     def fast_detect(self, gray, threshold=20, nms=True, cap=None):

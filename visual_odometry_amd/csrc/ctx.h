@@ -86,6 +86,13 @@ struct vo_ctx {
     std::vector<size_t> coef_x, coef_y;  // per level offsets into d_coef (uint32 units)
     std::vector<int> coef_ldw, coef_rows;  // per level LDS tile of the resize kernel (dwords per row, rows)
 
+    // ---- tracker workspace ---------------------------------------------------------------
+    DevBuf d_tk_pyr[2];  // packed tracker pyramids of two images (the last `next` image stays cached)
+    DevBuf d_tk_deriv;   // short2 per pixel: Scharr derivatives of the `prev` pyramid, zero frame
+    TrackGeom tk_geom;
+    int tk_w = 0, tk_h = 0, tk_win_w = 0, tk_win_h = 0, tk_max_level = -1;
+    int tk_last = -1;    // slot of d_tk_pyr holding the pyramid of the last call's `next` image
+
     // ---- matcher workspace ---------------------------------------------------------------
     DevBuf d_q, d_t;    // descriptor uploads (host-pointer entry points)
     DevBuf d_part;      // uint2 [pair][split][nq_cap]

@@ -1,0 +1,252 @@
+// k_track.hip — gfx950 kernels for cv::SparsePyrLKOpticalFlow::calc (pyramidal Lucas-Kanade,
+// cv 3.4 video/src/lkpyramid.cpp) as FeatureTracker::trackPoints calls it
+// (reference: src/features/feature_tracker.cpp:6,13).
+//
+//   k_lk_level0    caller's image -> level 0 of the tracker pyramid, with a reflect-101 frame
+//   k_lk_pyrdown   level l from level l-1: cv::pyrDown (5x5 binomial, (sum + 128) >> 8), frame included
+//   k_lk_scharr    calcSharrDeriv: (dx, dy) shorts per pixel; the frame of the derivative image is
+//                  zero (copyMakeBorder BORDER_CONSTANT) and is never written after allocation
+//   k_lk_track     one wavefront per point, all levels in one launch: 14-bit fixed-point bilinear
+//                  window of I and its derivatives into LDS (shorts), exact integer sums of the
+//                  products reduced across the wave (the sums do not depend on the order, so the
+//                  result equals the sequential CPU loop bit for bit), then <= 30 iterations that
+//                  resample J, all in cv's float expression order (-ffp-contract=off)
+// Every level lives in one packed buffer per image with a frame of TK_PAD pixels on all sides
+// (>= the window, so a window that hangs over the edge reads real memory, as cv's bordered
+// pyramid does).
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int tk_reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+__device__ __forceinline__ const uint8_t* tk_px(const uint8_t* buf, const TrackLevel& L) {
+    return buf + L.offset + (size_t)TK_PAD * L.pitch + TK_PAD;
+}
+__device__ __forceinline__ uint8_t* tk_px(uint8_t* buf, const TrackLevel& L) {
+    return buf + L.offset + (size_t)TK_PAD * L.pitch + TK_PAD;
+}
+
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+}  // namespace
+
+// one thread per aligned dword of the padded level
+__global__ __launch_bounds__(256) void k_lk_level0(const uint8_t* __restrict__ img, int stride, TrackGeom g,
+                                                   uint8_t* __restrict__ pyr) {
+    const TrackLevel L = g.lv[0];
+    const int x4 = -TK_PAD + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = -TK_PAD + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= L.w + TK_PAD || y >= L.h + TK_PAD) return;
+    const uint8_t* src = img + (size_t)tk_reflect101(y, L.h) * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (uint32_t)src[tk_reflect101(x4 + j, L.w)] << (8 * j);
+    *reinterpret_cast<uint32_t*>(tk_px(pyr, L) + (ptrdiff_t)y * L.pitch + x4) = v;
+}
+
+// The source level carries its reflect-101 frame, so source indices 2x-2 .. 2x+2 need no border
+// logic; frame pixels of the new level are the values at the reflected destination coordinate.
+__global__ __launch_bounds__(256) void k_lk_pyrdown(TrackGeom g, uint8_t* __restrict__ pyr, int level) {
+    const TrackLevel D = g.lv[level], S = g.lv[level - 1];
+    const int x4 = -TK_PAD + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = -TK_PAD + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x4 >= D.w + TK_PAD || y >= D.h + TK_PAD) return;
+    const uint8_t* s = tk_px((const uint8_t*)pyr, S);
+    const int ry = tk_reflect101(y, D.h);
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int rx = tk_reflect101(x4 + j, D.w);
+        int sum = 0;
+#pragma unroll
+        for (int ky = 0; ky < 5; ky++) {
+            const uint8_t* r = s + (ptrdiff_t)(2 * ry + ky - 2) * S.pitch + 2 * rx;
+            const int row = r[-2] + r[2] + 4 * (r[-1] + r[1]) + 6 * r[0];
+            sum += (ky == 0 || ky == 4 ? 1 : (ky == 2 ? 6 : 4)) * row;
+        }
+        out |= (uint32_t)((sum + 128) >> 8) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(tk_px(pyr, D) + (ptrdiff_t)y * D.pitch + x4) = out;
+}
+
+// interior pixels only; reads the reflect-101 frame of the image for the edge rows / columns
+__global__ __launch_bounds__(256) void k_lk_scharr(TrackGeom g, const uint8_t* __restrict__ pyr,
+                                                   short2* __restrict__ deriv, int level) {
+    const TrackLevel L = g.lv[level];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= L.w || y >= L.h) return;
+    const uint8_t* p = tk_px(pyr, L) + (ptrdiff_t)y * L.pitch + x;
+    const int pitch = L.pitch;
+    int t0[3], t1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int a = p[-pitch + k - 1], b = p[k - 1], c = p[pitch + k - 1];
+        t0[k] = (a + c) * 3 + b * 10;
+        t1[k] = c - a;
+    }
+    const size_t o = L.offset + (size_t)(y + TK_PAD) * L.pitch + TK_PAD + x;
+    deriv[o] = make_short2((short)(t0[2] - t0[0]), (short)((t1[2] + t1[0]) * 3 + t1[1] * 10));
+}
+
+#define TK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+__global__ __launch_bounds__(256) void k_lk_track(TrackGeom g, const uint8_t* __restrict__ pyrI,
+                                                  const short2* __restrict__ deriv,
+                                                  const uint8_t* __restrict__ pyrJ,
+                                                  const float2* __restrict__ prev_pts, float2* __restrict__ next_pts,
+                                                  uint8_t* __restrict__ status, int n, LkArgs a) {
+    extern __shared__ int16_t lk_lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wv;
+    if (pt >= n) return;  // a whole wave leaves; the kernel has no block-wide barrier
+    const int ww = a.win_w, wh = a.win_h, area = ww * wh;
+    int16_t* Iw = lk_lds + (size_t)wv * area * 3;
+    int16_t* Dx = Iw + area;
+    int16_t* Dy = Dx + area;
+    const float2 p = prev_pts[pt];
+    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const long long cn = a.channels;
+    float2 np = make_float2(0.f, 0.f);
+    bool ok = true;
+    for (int level = g.nlevels - 1; level >= 0; level--) {
+        const TrackLevel L = g.lv[level];
+        const float sc = __int_as_float((127 - level) << 23);  // (float)(1. / (1 << level))
+        float px = p.x * sc, py = p.y * sc;
+        if (level == g.nlevels - 1) np = make_float2(px, py);
+        else np = make_float2(np.x * 2.f, np.y * 2.f);
+        px -= half_x;
+        py -= half_y;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -ww || ipx >= L.w || ipy < -wh || ipy >= L.h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float fa = px - ipx, fb = py - ipy;
+        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        const int pitch = L.pitch;
+        {
+            const uint8_t* I0 = tk_px(pyrI, L) + (ptrdiff_t)ipy * pitch + ipx;
+            const short2* D0 = deriv + L.offset + (size_t)(ipy + TK_PAD) * pitch + TK_PAD + ipx;
+            int sA11 = 0, sA12 = 0, sA22 = 0;  // per lane: <= 16 terms below 2^25
+            for (int i = lane; i < area; i += 64) {
+                const int y = i / ww, x = i - y * ww;
+                const uint8_t* s = I0 + y * pitch + x;
+                const short2* d = D0 + y * pitch + x;
+                const int ival = TK_DESCALE(s[0] * iw00 + s[1] * iw01 + s[pitch] * iw10 + s[pitch + 1] * iw11, W_BITS - 5);
+                const short2 d00 = d[0], d01 = d[1], d10 = d[pitch], d11 = d[pitch + 1];
+                const int ixval = TK_DESCALE(d00.x * iw00 + d01.x * iw01 + d10.x * iw10 + d11.x * iw11, W_BITS);
+                const int iyval = TK_DESCALE(d00.y * iw00 + d01.y * iw01 + d10.y * iw10 + d11.y * iw11, W_BITS);
+                Iw[i] = (int16_t)ival;
+                Dx[i] = (int16_t)ixval;
+                Dy[i] = (int16_t)iyval;
+                sA11 += ixval * ixval;
+                sA12 += ixval * iyval;
+                sA22 += iyval * iyval;
+            }
+            const long long iA11 = wave_sum((long long)sA11), iA12 = wave_sum((long long)sA12),
+                            iA22 = wave_sum((long long)sA22);
+            const float A11 = __ll2float_rn(iA11 * cn) * FLT_SCALE, A12 = __ll2float_rn(iA12 * cn) * FLT_SCALE,
+                        A22 = __ll2float_rn(iA22 * cn) * FLT_SCALE;
+            float D = A11 * A22 - A12 * A12;
+            const float minEig =
+                (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
+            if (minEig < a.min_eig || D < 1.1920928955078125e-07F) {
+                if (level == 0) ok = false;
+                continue;
+            }
+            D = 1.f / D;
+            const uint8_t* Jb = tk_px(pyrJ, L);
+            float nx = np.x - half_x, ny = np.y - half_y;
+            float pdx = 0.f, pdy = 0.f;
+            for (int j = 0; j < a.max_count; j++) {
+                const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+                if (inx < -ww || inx >= L.w || iny < -wh || iny >= L.h) {
+                    if (level == 0) ok = false;
+                    break;
+                }
+                fa = nx - inx;
+                fb = ny - iny;
+                iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+                iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+                iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+                iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+                const uint8_t* J0 = Jb + (ptrdiff_t)iny * pitch + inx;
+                int sb1 = 0, sb2 = 0;  // per lane: <= 16 terms below 2^26
+                for (int i = lane; i < area; i += 64) {
+                    const int y = i / ww, x = i - y * ww;
+                    const uint8_t* s = J0 + y * pitch + x;
+                    const int diff =
+                        TK_DESCALE(s[0] * iw00 + s[1] * iw01 + s[pitch] * iw10 + s[pitch + 1] * iw11, W_BITS - 5) - Iw[i];
+                    sb1 += diff * Dx[i];
+                    sb2 += diff * Dy[i];
+                }
+                const long long ib1 = wave_sum((long long)sb1), ib2 = wave_sum((long long)sb2);
+                const float b1 = __ll2float_rn(ib1 * cn) * FLT_SCALE, b2 = __ll2float_rn(ib2 * cn) * FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+                nx += dx;
+                ny += dy;
+                np = make_float2(nx + half_x, ny + half_y);
+                if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
+                if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                    np.x -= dx * 0.5f;
+                    np.y -= dy * 0.5f;
+                    break;
+                }
+                pdx = dx;
+                pdy = dy;
+            }
+        }
+    }
+    if (lane == 0) {
+        next_pts[pt] = np;
+        status[pt] = ok ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr) {
+    {
+        const TrackLevel& L = g.lv[0];
+        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4));
+        hipLaunchKernelGGL(k_lk_level0, grid, dim3(256), 0, st, img, stride, g, pyr);
+    }
+    for (int l = 1; l < g.nlevels; l++) {
+        const TrackLevel& L = g.lv[l];
+        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4));
+        hipLaunchKernelGGL(k_lk_pyrdown, grid, dim3(256), 0, st, g, pyr, l);
+    }
+}
+
+void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv) {
+    for (int l = 0; l < g.nlevels; l++) {
+        const TrackLevel& L = g.lv[l];
+        dim3 grid(cdiv(L.w, 64), cdiv(L.h, 4));
+        hipLaunchKernelGGL(k_lk_scharr, grid, dim3(256), 0, st, g, pyr, deriv, l);
+    }
+}
+
+void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, const short2* deriv,
+                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
+                     const LkArgs& a) {
+    if (n <= 0) return;
+    const size_t lds = (size_t)4 * a.win_w * a.win_h * 3 * sizeof(int16_t);
+    hipLaunchKernelGGL(k_lk_track, dim3(cdiv(n, 4)), dim3(256), lds, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts,
+                       status, n, a);
+}

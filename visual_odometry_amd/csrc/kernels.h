@@ -109,6 +109,35 @@ void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, co
 void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,
                    const int* nkp, int kp_cap, int max_n, uint8_t* desc, int nframes);
 
+// ---- tracker ------------------------------------------------------------------------------
+// Tracker pyramid (cv::buildOpticalFlowPyramid): every level with a frame of TK_PAD pixels on all
+// sides, rows `pitch` (multiple of 64) bytes apart, all levels of an image in one packed buffer.
+// The derivative image (short2 per pixel) uses the same pixel indices.
+#define TK_PAD 32
+#define TK_MAX_LEVELS 8
+struct TrackLevel {
+    int w, h;
+    int pitch;
+    unsigned offset;  // pixel index of the padded level inside the packed buffer
+};
+struct TrackGeom {
+    int nlevels;
+    unsigned bytes;  // packed pixels per image
+    TrackLevel lv[TK_MAX_LEVELS];
+};
+struct LkArgs {
+    int win_w, win_h;
+    int max_count;
+    int channels;
+    float min_eig;
+    double eps2;
+};
+void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr);
+void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv);
+void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, const short2* deriv,
+                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
+                     const LkArgs& a);
+
 // ---- matcher ------------------------------------------------------------------------------
 // Packed neighbour key: distance << 23 | train index (numeric order == (distance, index) order).
 #define VO_KEY_INVALID 0xffffffffu

@@ -80,6 +80,7 @@ int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
     vo_ctx* c = new vo_ctx();
     c->device = device;
     c->err[0] = 0;
+    memset(&c->tk_geom, 0, sizeof(c->tk_geom));
     if (limits) c->lim = *limits;
     else vo_limits_default(&c->lim);
     if (c->lim.max_points > 65535 || c->lim.max_features > 262143 || c->lim.max_points < 5 ||
@@ -106,7 +107,8 @@ void vo_ctx_destroy(vo_ctx* c) {
                      &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,
                      &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
                      &c->d_state, &c->d_mask,   &c->d_q4,    &c->d_cmask,  &c->d_pose,   &c->d_pmask,
-                     &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj};
+                     &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj,
+                     &c->d_tk_pyr[0], &c->d_tk_pyr[1], &c->d_tk_deriv};
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
