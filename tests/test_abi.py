@@ -34,6 +34,10 @@ def test_struct_layouts():
     assert C.sizeof(_lib.OrbParams) == 36
     assert C.sizeof(_lib.PairParams) == 36 + 4 + 4 + 4 + 8 * 3 + 8 + 8  # with alignment padding
     assert C.sizeof(_lib.PairResult) == 24 + 8 * 21
+    assert C.sizeof(_lib.LkParams) == 40  # vo_lk_params: 4 ints, 2 doubles, 2 ints
+    lk = api.lk_params()
+    assert (lk.win_w, lk.win_h, lk.max_level, lk.max_count, lk.channels) == (21, 21, 3, 30, 3)
+    assert lk.epsilon == 0.01 and lk.min_eig_threshold == 1e-4
     p = api.orb_params(2000)
     assert (p.nfeatures, p.nlevels, p.edge_threshold, p.patch_size, p.fast_threshold) == (2000, 8, 31, 31, 20)
     assert abs(p.scale_factor - 1.2) < 1e-6

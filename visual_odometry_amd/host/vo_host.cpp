@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 
 #include "feature_detector.h"
@@ -365,3 +366,345 @@ int updatePose(const vo::Matd& K, VOFrame* last_frame, VOFrame* new_frame) {
     new_frame->pose = last_frame->pose;
     return 1;
 }
+
+// ---- FeatureTracker ---------------------------------------------------------------------------
+#include <atomic>
+#include <cstdio>
+#include <fstream>
+#include <numeric>
+#include <sstream>
+
+#include "feature_tracker.h"
+#include "kitti.h"
+#include "utils.h"
+#include "visual_odometry.h"
+#include "vo_host_c.h"
+
+uint64_t vo::Image::next_id() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1);
+}
+
+FeatureTracker::FeatureTracker(int channels) {
+    const char* e = std::getenv("VO_HIP_DEVICE");
+    const int rc = vo_ctx_create(e ? std::atoi(e) : 0, nullptr, &ctx_);
+    if (rc != VO_OK || !ctx_)
+        throw vo::Error(rc, "vo_ctx_create failed: no usable HIP device (there is no CPU fallback)");
+    vo_lk_params_default(&lk_);
+    lk_.channels = channels;
+}
+
+FeatureTracker::~FeatureTracker() {
+    if (ctx_) vo_ctx_destroy(ctx_);
+}
+
+float FeatureTracker::trackPoints(VOFrame* vo0, VOFrame* vo1) {
+    const vo::Image& a = vo0->image;
+    const vo::Image& b = vo1->image;
+    if (a.width != b.width || a.height != b.height || a.empty())
+        throw vo::Error(VO_ERR_INVALID, "trackPoints: images differ in size or are empty");
+    const int n = (int)vo0->points.size();
+    std::vector<unsigned char> status(n);
+    vo1->points.resize(n);
+    const bool cached = cached_id_ != 0 && cached_id_ == a.id;
+    cached_id_ = 0;
+    static_assert(sizeof(vo::Point2f) == 8, "packed points");
+    check(ctx_, vo_lk_track(ctx_, cached ? nullptr : a.px.data(), b.px.data(), a.width, a.height, a.width,
+                            n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
+                            n ? status.data() : nullptr));
+    cached_id_ = b.id;
+    // Remove bad points
+    return (float)removePoints(vo0, vo1, &status);
+}
+
+// The reference erases from the back of every vector inside the loop; an erase at index i only
+// moves elements behind i, which the loop has already visited, so every decision sees original
+// data and the result is this stable compaction.  `dists` is sorted first and then erased by the
+// ORIGINAL point index: kept as is (utils.h:16,42,57).
+int removePoints(VOFrame* vo0, VOFrame* vo1, std::vector<unsigned char>* status) {
+    const size_t n = status->size();
+    std::vector<float> orig(n);
+    for (size_t i = 0; i < n; i++) {
+        const float dx = vo0->points[i].x - vo1->points[i].x, dy = vo0->points[i].y - vo1->points[i].y;
+        orig[i] = (float)std::sqrt((double)dx * dx + (double)dy * dy);  // cv::norm(Point2f) -> double -> float
+    }
+    std::vector<float> dists = orig;
+    std::sort(dists.begin(), dists.end());
+    const double sum = std::accumulate(dists.begin(), dists.end(), 0.0);
+    const double mean = sum / dists.size();
+    const double sq_sum = std::inner_product(dists.begin(), dists.end(), dists.begin(), 0.0);
+    const double stdev = std::sqrt(sq_sum / dists.size() - mean * mean);
+
+    std::vector<uint8_t>& mask = vo0->mask.d;
+    const size_t n3 = vo0->points_3d.size(), nm = mask.size();
+    size_t k = 0, k3 = 0, km = 0;
+    std::vector<float> kept;
+    kept.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        const vo::Point2f pt = vo1->points[i];
+        const float dist = orig[i];
+        if ((*status)[i] == 0 || pt.x < 0 || pt.y < 0 || std::abs(dist - mean) > stdev * 2) {
+            if (pt.x < 0 || pt.y < 0) (*status)[i] = 0;
+            continue;
+        }
+        vo0->points[k] = vo0->points[i];
+        vo1->points[k] = pt;
+        k++;
+        kept.push_back(dists[i]);
+        if (i < n3) vo0->points_3d[k3++] = vo0->points_3d[i];
+        if (i < nm) mask[km++] = mask[i];
+    }
+    for (size_t i = n; i < n3; i++) vo0->points_3d[k3++] = vo0->points_3d[i];
+    for (size_t i = n; i < nm; i++) mask[km++] = mask[i];
+    vo0->points.resize(k);
+    vo1->points.resize(k);
+    vo0->points_3d.resize(k3);
+    mask.resize(km);
+    return kept.empty() ? 0 : (int)kept[kept.size() / 2];  // empty: undefined behaviour in the reference
+}
+
+// ---- VisualOdometry ---------------------------------------------------------------------------
+VisualOdometry::VisualOdometry(const vo::Matd& K, size_t min_tracked_points, bool ba, int tracker_channels)
+    : feature_tracker_(tracker_channels) {
+    if (ba)
+        throw vo::Error(VO_ERR_INVALID,
+                        "VisualOdometry: bundle adjustment (GTSAM back end) is not part of the accelerated path");
+    tracking_ = false;
+    min_tracked_points_ = min_tracked_points;
+    K_ = K;
+}
+
+void VisualOdometry::addImage(const vo::Image& image, vo::Matd* pose, vo::Matd* /*pose_kalman*/) {
+    VOFrame frame;
+    frame.setImage(image);
+    if (frame_buffer_.size() == kFrameBufferCapacity) frame_buffer_.pop_front();  // circular_buffer overwrite
+    frame_buffer_.push_back(std::move(frame));
+    if (frame_buffer_.size() != kFrameBufferCapacity) return;
+
+    VOFrame& vo1 = frame_buffer_[frame_buffer_.size() - 2];
+    VOFrame& vo2 = frame_buffer_[frame_buffer_.size() - 1];
+
+    if (!tracking_) {
+        feature_detector_.detectFAST(&vo1);
+        tracking_ = true;
+    }
+
+    if (feature_tracker_.trackPoints(&vo1, &vo2) < 0) {  // never true in the reference either
+        frame_buffer_.pop_back();
+        return;
+    }
+
+    if (vo2.points.size() < min_tracked_points_) tracking_ = false;
+
+    updatePose(K_, &vo1, &vo2);
+
+    (*pose) = vo2.pose;
+}
+
+// ---- KITTI formats ------------------------------------------------------------------------------
+vo::Matd loadKittiCalibration(std::string calib_file, int line_number) {
+    std::string line;
+    std::ifstream file_stream(calib_file);
+    if (!file_stream.is_open()) throw vo::Error(VO_ERR_INVALID, "Unable to open file " + calib_file);
+    int count = 0;
+    while (std::getline(file_stream, line)) {
+        if (count == line_number) break;
+        count++;
+    }
+    line.erase(0, std::min<size_t>(4, line.size()));
+    // boost::algorithm::split(elements, line, is_any_of(" ")): empty tokens are kept and std::stod
+    // throws on them, as the reference would
+    double data[12] = {0};
+    size_t pos = 0;
+    int i = 0;
+    for (;;) {
+        const size_t sp = line.find(' ', pos);
+        const std::string tok = line.substr(pos, sp == std::string::npos ? std::string::npos : sp - pos);
+        if (i >= 12) throw vo::Error(VO_ERR_INVALID, "calibration line holds more than 12 values");
+        try {
+            data[i++] = std::stod(tok);
+        } catch (const std::exception&) {
+            throw vo::Error(VO_ERR_INVALID, "calibration line: '" + tok + "' is not a number");
+        }
+        if (sp == std::string::npos) break;
+        pos = sp + 1;
+    }
+    vo::Matd K(3, 3);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) K(r, c) = data[4 * r + c];
+    return K;
+}
+
+vo::Matd kittiResultMat(const vo::Matd& pose) {
+    vo::Matd m = vo::Matd::eye(4, 4);
+    for (int r = 0; r < pose.rows; r++)
+        for (int c = 0; c < pose.cols; c++) m(r, c) = pose(r, c);
+    return m;
+}
+
+std::vector<vo::Matd> loadPoses(const std::string& file_name) {
+    std::vector<vo::Matd> poses;
+    FILE* fp = fopen(file_name.c_str(), "r");
+    if (!fp) return poses;
+    while (!feof(fp)) {
+        vo::Matd P = vo::Matd::eye(4, 4);
+        if (fscanf(fp, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", &P(0, 0), &P(0, 1), &P(0, 2), &P(0, 3),
+                   &P(1, 0), &P(1, 1), &P(1, 2), &P(1, 3), &P(2, 0), &P(2, 1), &P(2, 2), &P(2, 3)) == 12)
+            poses.push_back(P);
+    }
+    fclose(fp);
+    return poses;
+}
+
+void savePoses(const std::string& file_name, const std::vector<vo::Matd>& poses) {
+    FILE* fp = fopen(file_name.c_str(), "w");
+    if (!fp) throw vo::Error(VO_ERR_INVALID, "Unable to open file " + file_name);
+    for (const auto& P : poses) {
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) fprintf(fp, "%.9e%s", P(r, c), (r == 2 && c == 3) ? "\n" : " ");
+    }
+    fclose(fp);
+}
+
+// ---- C entry points over the driver ---------------------------------------------------------------
+struct vo_host_vo {
+    VisualOdometry* vo = nullptr;
+    vo::Matd pose = vo::Matd::eye(3, 4);
+};
+
+namespace {
+void set_err(char* err, int cap, const char* msg) {
+    if (err && cap > 0) snprintf(err, cap, "%s", msg);
+}
+}  // namespace
+
+extern "C" {
+
+vo_host_vo* vo_host_vo_create(const double* K, int min_tracked_points, uint32_t scale_seed, int tracker_channels,
+                              char* err, int err_cap) {
+    try {
+        vo::Matd Km(3, 3);
+        for (int i = 0; i < 9; i++) Km.d[i] = K[i];
+        vo_host_vo* v = new vo_host_vo();
+        v->vo = new VisualOdometry(Km, (size_t)min_tracked_points, false, tracker_channels);
+        setScaleSeed(scale_seed);
+        return v;
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return nullptr;
+    }
+}
+
+void vo_host_vo_destroy(vo_host_vo* v) {
+    if (!v) return;
+    delete v->vo;
+    delete v;
+}
+
+int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, double* pose, char* err, int err_cap) {
+    try {
+        vo::Image im;
+        im.width = w;
+        im.height = h;
+        im.px.assign(gray, gray + (size_t)w * h);
+        v->vo->addImage(im, &v->pose, nullptr);
+        for (int i = 0; i < 12; i++) pose[i] = v->pose.d[i];
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return -1;
+    }
+}
+
+int vo_host_vo_state(vo_host_vo* v, int* full, int* tracking, int* n_points, int* n_mask, float* scale) {
+    *full = v->vo->full() ? 1 : 0;
+    *tracking = v->vo->tracking() ? 1 : 0;
+    *n_points = *n_mask = 0;
+    *scale = 1.f;
+    if (!v->vo->full()) return 0;
+    const VOFrame& cur = v->vo->currentFrame();
+    *n_points = (int)cur.points.size();
+    *n_mask = cur.mask.rows();
+    *scale = cur.scale;
+    return 0;
+}
+
+int vo_host_vo_arrays(vo_host_vo* v, float* prev_pts, float* cur_pts, uint8_t* mask, double* E, double* local_R,
+                      double* local_t, double* points_3d) {
+    if (!v->vo->full()) return -1;
+    const VOFrame& prev = v->vo->previousFrame();
+    const VOFrame& cur = v->vo->currentFrame();
+    if (prev_pts && !prev.points.empty()) memcpy(prev_pts, prev.points.data(), prev.points.size() * sizeof(vo::Point2f));
+    if (cur_pts && !cur.points.empty()) memcpy(cur_pts, cur.points.data(), cur.points.size() * sizeof(vo::Point2f));
+    if (mask && !cur.mask.d.empty()) memcpy(mask, cur.mask.d.data(), cur.mask.d.size());
+    if (E && cur.E.d.size() == 9) memcpy(E, cur.E.d.data(), 9 * sizeof(double));
+    if (local_R && cur.local_R.d.size() == 9) memcpy(local_R, cur.local_R.d.data(), 9 * sizeof(double));
+    if (local_t && cur.local_t.d.size() == 3) memcpy(local_t, cur.local_t.d.data(), 3 * sizeof(double));
+    if (points_3d && !cur.points_3d.empty())
+        memcpy(points_3d, cur.points_3d.data(), cur.points_3d.size() * sizeof(vo::Point3d));
+    return 0;
+}
+
+int vo_host_load_calibration(const char* calib_file, int line_number, double* K, char* err, int err_cap) {
+    try {
+        const vo::Matd Km = loadKittiCalibration(calib_file, line_number);
+        for (int i = 0; i < 9; i++) K[i] = Km.d[i];
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return -1;
+    }
+}
+
+int vo_host_load_poses(const char* file_name, double* poses, int cap, int* n) {
+    const auto P = loadPoses(file_name);
+    *n = (int)P.size();
+    for (int i = 0; i < *n && i < cap; i++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) poses[12 * i + 4 * r + c] = P[i](r, c);
+    return 0;
+}
+
+int vo_host_save_poses(const char* file_name, const double* poses, int n) {
+    try {
+        std::vector<vo::Matd> P;
+        for (int i = 0; i < n; i++) {
+            vo::Matd m(3, 4);
+            for (int k = 0; k < 12; k++) m.d[k] = poses[12 * i + k];
+            P.push_back(m);
+        }
+        savePoses(file_name, P);
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+int vo_host_remove_points(float* p0, float* p1, int n, uint8_t* status, double* pts3d, int n3d, uint8_t* mask,
+                          int nmask, int* n_out, int* n3d_out, int* nmask_out, int* ret) {
+    VOFrame a, b;
+    a.points.resize(n);
+    b.points.resize(n);
+    if (n) {
+        memcpy(static_cast<void*>(a.points.data()), p0, (size_t)n * 8);
+        memcpy(static_cast<void*>(b.points.data()), p1, (size_t)n * 8);
+    }
+    a.points_3d.resize(n3d);
+    if (n3d) memcpy(static_cast<void*>(a.points_3d.data()), pts3d, (size_t)n3d * 24);
+    a.mask.d.assign(mask, mask + nmask);
+    std::vector<unsigned char> st(status, status + n);
+    *ret = removePoints(&a, &b, &st);
+    *n_out = (int)a.points.size();
+    if (*n_out) {
+        memcpy(p0, a.points.data(), a.points.size() * 8);
+        memcpy(p1, b.points.data(), b.points.size() * 8);
+    }
+    if (n) memcpy(status, st.data(), n);
+    *n3d_out = (int)a.points_3d.size();
+    if (*n3d_out) memcpy(pts3d, a.points_3d.data(), a.points_3d.size() * 24);
+    *nmask_out = (int)a.mask.d.size();
+    if (*nmask_out) memcpy(mask, a.mask.d.data(), a.mask.d.size());
+    return 0;
+}
+
+}  // extern "C"

@@ -71,7 +71,12 @@ Matd hconcat(const Matd& a, const Matd& b);
 struct Image {
     int width = 0, height = 0;
     std::vector<uint8_t> px;
+    // identity of the pixel content: copies share it, every newly made image gets a fresh one.  Lets
+    // the tracker see that a frame is the one it tracked into last time (its pyramid is still on the
+    // device).  Do not change px after the image was handed to a VOFrame.
+    uint64_t id = next_id();
     bool empty() const { return px.empty(); }
+    static uint64_t next_id();
 };
 
 // N x 32 CV_8U descriptor matrix
