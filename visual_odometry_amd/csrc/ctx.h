@@ -72,6 +72,8 @@ struct vo_ctx {
     DevBuf d_desc;    // uint8 [frame][kp_cap][32]
     DevBuf d_nkp;     // int [frame] (+1 spare)
     PinnedBuf h_lvlofs, h_cand, h_sel, h_nkp, h_misc, h_flags;
+    PinnedBuf h_img;  // two staging slots for vo_upload_image
+    int h_img_slot = 0;
     int max_cand = 65536;
     int last_flags = 0;  // OR of the VO_SEL_* flags of the last batch
     int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
@@ -155,6 +157,7 @@ struct vo_ctx {
 int vo_ensure(vo_ctx* ctx, DevBuf& b, size_t bytes);
 int vo_ensure_pinned(vo_ctx* ctx, PinnedBuf& b, size_t bytes);
 int vo_check_launch(vo_ctx* ctx, const char* what);
+int vo_upload_image(vo_ctx* c, DevBuf& dst, const uint8_t* gray, int w, int h, int stride);
 
 // features (vo_features.cpp)
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);

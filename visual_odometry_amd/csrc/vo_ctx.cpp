@@ -30,6 +30,21 @@ int vo_ensure_pinned(vo_ctx* ctx, PinnedBuf& b, size_t bytes) {
     return VO_OK;
 }
 
+// Host image (pageable memory, any stride) -> tightly packed device image.  Rows are gathered into a
+// pinned staging slot so that the transfer is one DMA; two slots alternate because an entry point
+// uploads at most two images (prev, next) before it synchronises.
+int vo_upload_image(vo_ctx* c, DevBuf& dst, const uint8_t* gray, int w, int h, int stride) {
+    const size_t bytes = (size_t)w * h;
+    VO_TRY(vo_ensure(c, dst, bytes));
+    VO_TRY(vo_ensure_pinned(c, c->h_img, 2 * bytes));
+    uint8_t* slot = c->h_img.as<uint8_t>() + (size_t)(c->h_img_slot ^= 1) * bytes;
+    if (stride == w) memcpy(slot, gray, bytes);
+    else
+        for (int y = 0; y < h; y++) memcpy(slot + (size_t)y * w, gray + (size_t)y * stride, w);
+    VO_HIP(c, hipMemcpyAsync(dst.p, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+
 int vo_check_launch(vo_ctx* ctx, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ctx->fail(VO_ERR_DEVICE, "%s: launch failed: %s", what, hipGetErrorString(e));
@@ -112,7 +127,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
-                        &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts};
+                        &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

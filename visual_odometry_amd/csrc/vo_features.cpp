@@ -400,9 +400,7 @@ int feat_orb_frames(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int st
 }
 
 static int upload_image(vo_ctx* c, const uint8_t* gray, int w, int h, int stride) {
-    VO_TRY(vo_ensure(c, c->d_img, (size_t)w * h));
-    VO_HIP(c, hipMemcpy2DAsync(c->d_img.p, w, gray, stride, w, h, hipMemcpyHostToDevice, c->stream));
-    return VO_OK;
+    return vo_upload_image(c, c->d_img, gray, w, h, stride);
 }
 
 extern "C" {

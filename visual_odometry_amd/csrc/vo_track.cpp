@@ -56,8 +56,7 @@ int track_setup(vo_ctx* c, int w, int h, const vo_lk_params* p) {
 }
 
 int track_pyramid(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, int slot) {
-    VO_TRY(vo_ensure(c, c->d_img, (size_t)w * h));
-    VO_HIP(c, hipMemcpy2DAsync(c->d_img.p, w, gray, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    VO_TRY(vo_upload_image(c, c->d_img, gray, w, h, stride));
     launch_lk_pyramid(c->stream, c->d_img.as<uint8_t>(), w, c->tk_geom, c->d_tk_pyr[slot].as<uint8_t>());
     return vo_check_launch(c, "tracker pyramid");
 }
