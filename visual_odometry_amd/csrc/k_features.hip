@@ -325,57 +325,52 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 }
 
 // ---------------------------------------------------------------------------------------------
-// Per frame: keypoints per row from the masks, exclusive scan over all rows of all levels ->
-// segbase[seg] = position of the first keypoint of that 64-pixel segment in the frame's
-// row-major candidate list; lvlofs[l] = first candidate of level l.  One block per frame.
+// Per frame: segbase[seg] = position of the first keypoint of that 64-pixel segment in the
+// frame's row-major candidate list; lvlofs[l] = first candidate of level l.  The mask table is
+// laid out level after level, row after row, segment after segment, i.e. in candidate order, so
+// this is one exclusive prefix sum of popcounts over a flat array.  One block of 16 waves per
+// frame; a wave owns a contiguous chunk, reads it with consecutive lanes on consecutive words
+// (pass 1: chunk total, pass 2: in-wave scans on top of the chunk's base).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g,
                                                    const unsigned long long* __restrict__ masks,
                                                    int* __restrict__ segbase, int* __restrict__ lvlofs) {
-    __shared__ int part[1024];
+    __shared__ int wtot[16];
     __shared__ int lvl[VO_ORB_MAX_LEVELS + 1];
-    const int f = blockIdx.x, t = threadIdx.x;
-    const int rows = g->rows_total;
-    const int per = (rows + 1023) / 1024;
-    const unsigned long long* M = masks + (size_t)f * g->segs_total;
-    int* SB = segbase + (size_t)f * g->segs_total;
+    const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int total = g->segs_total, nlevels = g->nlevels;
+    const int per = ((total + 15) / 16 + 63) & ~63;  // words per wave, whole wave iterations
+    const int beg = wv * per, end = min(total, beg + per);
+    const unsigned long long* M = masks + (size_t)f * total;
+    int* SB = segbase + (size_t)f * total;
     int sum = 0;
-    for (int i = 0; i < per; i++) {
-        const int r = t * per + i;
-        if (r < rows) {
-            int l = 0;
-            for (int k = 1; k < g->nlevels; k++)
-                if (r >= g->lv[k].row0) l = k;
-            const int s0 = g->lv[l].seg0 + (r - g->lv[l].row0) * g->lv[l].segs;
-            for (int s = 0; s < g->lv[l].segs; s++) sum += __popcll(M[s0 + s]);
-        }
-    }
-    part[t] = sum;
+    for (int i = beg + lane; i < end; i += 64) sum += __popcll(M[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) wtot[wv] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = part[t] - sum;
-    for (int i = 0; i < per; i++) {
-        const int r = t * per + i;
-        if (r < rows) {
-            int l = 0;
-            for (int k = 1; k < g->nlevels; k++)
-                if (r >= g->lv[k].row0) l = k;
-            if (r == g->lv[l].row0) lvl[l] = run;
-            const int s0 = g->lv[l].seg0 + (r - g->lv[l].row0) * g->lv[l].segs;
-            for (int s = 0; s < g->lv[l].segs; s++) {
-                SB[s0 + s] = run;
-                run += __popcll(M[s0 + s]);
-            }
+    int run = 0;
+    for (int k = 0; k < wv; k++) run += wtot[k];
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const int c = i < end ? __popcll(M[i]) : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
         }
+        if (i < end) {
+            const int base = run + inc - c;
+            SB[i] = base;
+            for (int l = 0; l < nlevels; l++)
+                if (i == g->lv[l].seg0) lvl[l] = base;
+        }
+        run += __shfl(inc, 63);
     }
-    if (t == 1023) lvl[g->nlevels] = part[1023];
+    if (wv == 15 && lane == 0) lvl[nlevels] = run;
     __syncthreads();
-    if (t <= g->nlevels) lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + t] = lvl[t];
+    if ((int)threadIdx.x <= nlevels) lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] = lvl[threadIdx.x];
 }
 
 // One thread per 64-pixel segment: its keypoints go to the candidate list in x order.
@@ -681,7 +676,7 @@ __global__ void k_sel_count(const PyrGeom* __restrict__ g, const int* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // IC angle: integer moments over the radius-15 disc (umax rows), fastAtan2, then the keypoint
-// is written in level-0 coordinates (pt *= scale).  One wave per keypoint, two disc rows per step.
+// is written in level-0 coordinates (pt *= scale).  One wave per keypoint.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float atan2_p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
@@ -735,24 +730,34 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
         cd = cand[(size_t)f * max_cand + idx];
     }
     const int pitch = g->lv[cd.level].pitch;
-    const uint8_t* center = level_px(pyr, g, f, cd.level) + (ptrdiff_t)cd.y * pitch + cd.x;
+    // The 31 x 31 patch is read as 31 rows x 9 aligned dwords (279 work items over the wave); a work
+    // item masks the bytes outside the disc and takes sum(b) and sum(j b) with two v_dot4_u32_u8:
+    // sum(u b) = u(first byte) sum(b) + sum(j b).  Integer sums: the same m10, m01 as a per-pixel loop.
+    const int xw = (cd.x - 15) & ~3, o = (cd.x - 15) - xw;
+    const uint8_t* base = level_px(pyr, g, f, cd.level) + (ptrdiff_t)cd.y * pitch + xw;
     int m01 = 0, m10 = 0;
-    const int u = (lane & 31) - 15;
-    const int au = u < 0 ? -u : u;
-#pragma unroll 4
-    for (int step = 0; step < 16; step++) {
-        const int v = -15 + 2 * step + (lane >> 5);
-        const int av = v < 0 ? -v : v;
-        if (v <= 15 && au <= 15 && au <= s_umax[av & 15]) {
-            const int val = center[v * pitch + u];
-            m10 += u * val;
-            m01 += v * val;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int item = lane + 64 * j;
+        if (item < 31 * 9) {
+            const int row = item / 9, k = item - row * 9;
+            const int v = row - 15, um = s_umax[v < 0 ? -v : v];
+            const int u0 = 4 * k - 15 - o;             // u of byte 0 of this dword
+            const int jlo = max(-um - u0, 0), jhi = min(um - u0, 3);
+            if (jlo <= jhi) {
+                const uint32_t mask = (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (3 - jhi)));
+                const uint32_t d = *reinterpret_cast<const uint32_t*>(base + v * pitch + 4 * k) & mask;
+                const int sb = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
+                const int sj = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
+                m10 += u0 * sb + sj;
+                m01 += v * sb;
+            }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        m10 += __shfl_xor(m10, o2);
+        m01 += __shfl_xor(m01, o2);
     }
     if (lane == 0) {
         const float s = g->lv[cd.level].scale;
