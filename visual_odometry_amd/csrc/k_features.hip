@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
                                                   int threshold, int border, int nms) {
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
-    __shared__ uint8_t sm[SM_H][SM_W + 2];
+    __shared__ __attribute__((aligned(4))) uint8_t sm[SM_H][SM_W + 2];
     __shared__ uint16_t listA[SM_W * SM_H];
     __shared__ uint16_t listB[SM_W * SM_H];
     __shared__ uint32_t rowmask[FT_H][2];
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         const int gx = min(max(tx0 - 4 + 4 * c4, -VO_PADX), pitch - VO_PADX - 4);
         px4[i] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
     }
-    for (int i = tid; i < SM_H * (SM_W + 2); i += 256) (&sm[0][0])[i] = 0;
+    static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
+    for (int i = tid; i < SM_H * (SM_W + 2) / 4; i += 256) reinterpret_cast<uint32_t*>(&sm[0][0])[i] = 0;
     if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
     if (tid == 0) {
         nA = 0;
