@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void k_pose_points(PoseState* __restrict__ ps,
         v = x2[(size_t)pair * n_cap + i];
     }
     const uint8_t min_ = (ok && mask_in) ? mask_in[(size_t)pair * n_cap + i] : 0xff;
-    for (int c = 0; c < 4; c++) {
+    {
+        const int c = blockIdx.z;  // one of the four (R, t) candidates per block: 4x the waves, 1/4 the latency
         bool m = false;
         if (ok) {
             double P1[12], X[4];
@@ -541,7 +542,7 @@ void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps
                  double dist, double* q4, uint8_t* cmask, uint8_t* mask_out, double* pts4, int npairs) {
     hipLaunchKernelGGL(k_pose_setup, dim3(cdiv(npairs, 64)), dim3(64), 0, st, E, e_stride, ps, npairs);
     if (n_grid > 0)
-        hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
+        hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs, 4), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
                            n_cap, mask_in, dist, q4, cmask);
     hipLaunchKernelGGL(k_pose_select, dim3(npairs), dim3(256), 0, st, ps, d_n, n_host, n_cap, q4, cmask, mask_out,
                        pts4);
