@@ -148,23 +148,35 @@ VO_HD int level_roots(const double (&c)[11], double bound, int nprev, const S& s
     int ncur = 0;
     double lo = nprev > 0 ? s(prev) : 0.0, flo, d;
     horner<D>(a, lo, flo, d);
-    if ((flo < 0) != neg_at_minf) {
-        double xin, xout, fout;
-        if (outward_bracket<D>(a, lo, flo, -1.0, bound, xin, xout, fout))
-            s(cur + ncur++) = bracket_root<D>(a, xout, xin, fout, tol);
-    }
-    for (int j = 1; j < nprev; j++) {
-        const double hi = s(prev + j);
-        double fhi;
-        horner<D>(a, hi, fhi, d);
-        if ((flo < 0) != (fhi < 0)) s(cur + ncur++) = bracket_root<D>(a, lo, hi, flo, tol);
-        lo = hi;
-        flo = fhi;
-    }
-    if ((flo < 0) != neg_at_pinf) {
-        double xin, xout, fout;
-        if (outward_bracket<D>(a, lo, flo, 1.0, bound, xin, xout, fout))
-            s(cur + ncur++) = bracket_root<D>(a, xin, xout, flo, tol);
+    // interval 0: (-inf, p0]; k = 1 .. npts-1: [p(k-1), p(k)]; npts: [p(npts-1), +inf).  One loop with
+    // one call site per helper: the kernel's code is larger than the instruction cache and mostly
+    // straight-line, so every inlined copy is paid for in instruction fetch misses.
+    const int npts = nprev > 0 ? nprev : 1;
+    for (int k = 0; k <= npts; k++) {
+        double blo = 0, bhi = 0, bf = 0;
+        bool have;
+        if (k == 0 || k == npts) {
+            const bool left = k == 0;
+            have = (flo < 0) != (left ? neg_at_minf : neg_at_pinf);
+            if (have) {
+                double xin, xout, fout;
+                have = outward_bracket<D>(a, lo, flo, left ? -1.0 : 1.0, bound, xin, xout, fout);
+                blo = left ? xout : xin;
+                bhi = left ? xin : xout;
+                bf = left ? fout : flo;
+            }
+        } else {
+            const double hi = s(prev + k);
+            double fhi;
+            horner<D>(a, hi, fhi, d);
+            have = (flo < 0) != (fhi < 0);
+            blo = lo;
+            bhi = hi;
+            bf = flo;
+            lo = hi;
+            flo = fhi;
+        }
+        if (have) s(cur + ncur++) = bracket_root<D>(a, blo, bhi, bf, tol);
     }
     return ncur;
 }

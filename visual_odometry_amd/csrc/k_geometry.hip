@@ -14,6 +14,8 @@
 //                   cheirality masks, winner selection
 // Reference call sites: src/matcher/matcher.cpp:42, src/visual_odometry/vo_pose.h:14,19,
 // src/sfm/triangulation.cpp:64.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "geom_types.h"
 #include "five_point.h"
@@ -500,10 +502,14 @@ void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint
                    int npairs) {
     int lanes = 64;
     while (lanes > 4 && (long)(h1 - h0) * npairs / lanes < 1024) lanes /= 2;
+    static const int env_lanes = getenv("VO_SOLVE_LANES") ? atoi(getenv("VO_SOLVE_LANES")) : 0;
+    if (env_lanes) lanes = env_lanes;
 #define VO_SOLVE5(L)                                                                                           \
     hipLaunchKernelGGL(k_solve5<L>, dim3(cdiv(h1 - h0, L), npairs), dim3(L), 0, st, h0, h1, s, samples, samples_iters, \
                        x1, x2, n_cap, models, nmodels, H)
     switch (lanes) {
+        case 1: VO_SOLVE5(1); break;
+        case 2: VO_SOLVE5(2); break;
         case 4: VO_SOLVE5(4); break;
         case 8: VO_SOLVE5(8); break;
         case 16: VO_SOLVE5(16); break;
