@@ -64,15 +64,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=3, help="chunks in flight (HIP streams)")
-    ap.add_argument("--chunk", type=int, default=32, help="frame pairs per chunk")
-    ap.add_argument("--frames", type=int, default=0, help="frames per step (default streams*chunk + 1)")
+    ap.add_argument("--chunk", type=int, default=48, help="frame pairs per chunk")
+    ap.add_argument("--frames", type=int, default=0, help="frames per step (default 6 chunks: 6*chunk + 1)")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
     args = ap.parse_args()
 
     if args.frames <= 0:
-        args.frames = args.streams * args.chunk + 1
+        args.frames = 6 * args.chunk + 1  # two rounds of chunks per stream: the pipeline reaches steady state
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
