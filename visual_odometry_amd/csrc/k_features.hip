@@ -340,32 +340,54 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
     __shared__ int lvl[VO_ORB_MAX_LEVELS + 1];
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = g->segs_total, nlevels = g->nlevels;
-    const int per = ((total + 15) / 16 + 63) & ~63;  // words per wave, whole wave iterations
+    const int per = ((total + 15) / 16 + 511) & ~511;  // words per wave, whole steps of 512
     const int beg = wv * per, end = min(total, beg + per);
     const unsigned long long* M = masks + (size_t)f * total;
     int* SB = segbase + (size_t)f * total;
+    // a lane owns eight consecutive words (64 bytes) per step of 512: serial prefix inside the lane,
+    // one wave scan per step
     int sum = 0;
-    for (int i = beg + lane; i < end; i += 64) sum += __popcll(M[i]);
+    for (int i0 = beg; i0 < end; i0 += 512) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 8 * lane + u;
+            sum += i < end ? __popcll(M[i]) : 0;
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) wtot[wv] = sum;
     __syncthreads();
     int run = 0;
     for (int k = 0; k < wv; k++) run += wtot[k];
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const int c = i < end ? __popcll(M[i]) : 0;
-        int inc = c;
+    int seg0[VO_ORB_MAX_LEVELS];  // level starts, in registers for the loop below
+#pragma unroll
+    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) seg0[l] = l < nlevels ? g->lv[l].seg0 : -1;
+    for (int i0 = beg; i0 < end; i0 += 512) {
+        const int ib = i0 + 8 * lane;
+        int c[8], t = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            c[u] = ib + u < end ? __popcll(M[ib + u]) : 0;
+            t += c[u];
+        }
+        int inc = t;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
+            const int v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
         }
-        if (i < end) {
-            const int base = run + inc - c;
-            SB[i] = base;
-            for (int l = 0; l < nlevels; l++)
-                if (i == g->lv[l].seg0) lvl[l] = base;
+        int base = run + inc - t;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = ib + u;
+            if (i < end) {
+                SB[i] = base;
+#pragma unroll
+                for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
+                    if (i == seg0[l]) lvl[l] = base;
+            }
+            base += c[u];
         }
         run += __shfl(inc, 63);
     }
