@@ -183,14 +183,24 @@ def main():
     nc = min(args.chunk, n - 1)  # pairs per matcher launch
     algo_bytes = sum(scan_bytes(nkp[p], nkp[p + 1]) for p in range(nc))
     ctx.prof_enable(True)
-    for which in (0, 1, 2):
+    for which in (0, 1, 2, 3):
         ctx.prof_get(which, True)
     for _ in range(5):
         ctx.pairs_run_dev(d_frames.data_ptr(), nc + 1, w, h, w, w * h, K, params)
     knn_n, knn_ms = ctx.prof_get(0)
     fast_n, fast_ms = ctx.prof_get(1)
     solve_n, solve_ms = ctx.prof_get(2)
+    feat_n, feat_ms = ctx.prof_get(3)
     ctx.prof_enable(False)
+    # detector + descriptor stage (pyramid .. rBRIEF) against its algorithmic bytes (SURVEY.md 8d:
+    # W*H + 4*P + K*60 per frame, P = pyramid pixels): HBM-bound in the limit, VALU / latency bound today
+    pyr_px = sum(int(round(w / 1.2 ** l)) * int(round(h / 1.2 ** l)) for l in range(8))
+    feat_bytes = sum(w * h + 4 * pyr_px + k * 60 for k in nkp[: nc + 1])
+    feat_s = feat_ms / max(feat_n, 1) * 1e-3
+    detector = {"stage": "pyramid + FAST/NMS + selection + IC angle + blur + rBRIEF, %d frames per batch" % (nc + 1),
+                "bound": "hbm", "achieved": feat_bytes / feat_s / 1e9 if feat_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": feat_bytes / feat_s / 1e9 / HBM_PEAK_GBS if feat_s > 0 else 0.0,
+                "algorithmic_bytes_per_batch": feat_bytes, "avg_batch_us": feat_s * 1e6}
     knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
     achieved = algo_bytes / knn_avg_s / 1e9 if knn_avg_s > 0 else 0.0
     traffic = None
@@ -256,6 +266,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
+            "detector_roofline": detector,
             "stage_us_per_step": {"fast_score_kernel": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
                                   "knn2_partial_kernel": knn_avg_s * 1e6,
                                   "solve5_kernels_per_step": solve_ms / 5 * 1e3},

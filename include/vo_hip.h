@@ -194,7 +194,8 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
 #define VO_PROF_KNN 0
 #define VO_PROF_FAST 1
 #define VO_PROF_SOLVE 2
-#define VO_PROF_COUNT 3
+#define VO_PROF_FEATURES 3  /* vo_pairs_run_dev: everything from the pyramid to the descriptors of a batch */
+#define VO_PROF_COUNT 4
 int vo_prof_enable(vo_ctx* ctx, int on);
 
 /* Tuning / test knobs of a context (no reference counterpart).

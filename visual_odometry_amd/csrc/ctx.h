@@ -51,7 +51,7 @@ struct vo_ctx {
     char err[512];
     bool prof_on = false;
     ProfSlot prof[VO_PROF_COUNT];
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0[VO_PROF_COUNT] = {}, ev1[VO_PROF_COUNT] = {};  // per slot: brackets may nest
 
     // ---- feature workspace (per frame strides: geom.pyr_bytes, max_cand, kp_cap) ---------
     DevBuf d_img;     // uploaded frames (host-pointer entry points)
@@ -192,14 +192,14 @@ struct ProfScope {
     int which;
     bool on;
     ProfScope(vo_ctx* ctx, int w) : c(ctx), which(w), on(ctx->prof_on) {
-        if (on) (void)hipEventRecord(c->ev0, c->stream);
+        if (on) (void)hipEventRecord(c->ev0[which], c->stream);
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
+        (void)hipEventRecord(c->ev1[which], c->stream);
+        (void)hipEventSynchronize(c->ev1[which]);
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        (void)hipEventElapsedTime(&ms, c->ev0[which], c->ev1[which]);
         c->prof[which].launches++;
         c->prof[which].total_ms += ms;
     }

@@ -103,9 +103,11 @@ int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
         delete c;
         return VO_ERR_INVALID;
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < VO_PROF_COUNT; i++)
+        ok = hipEventCreate(&c->ev0[i]) == hipSuccess && hipEventCreate(&c->ev1[i]) == hipSuccess;
+    if (!ok) {
+        vo_ctx_destroy(c);
         return VO_ERR_DEVICE;
     }
     *out = c;
@@ -130,8 +132,10 @@ void vo_ctx_destroy(vo_ctx* c) {
                         &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < VO_PROF_COUNT; i++) {
+        if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+        if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -66,11 +66,14 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
     c->pipe_frames = 0;
     c->pend_frames = 0;
     VO_TRY(feat_setup(c, w, h, &prm->orb, n_frames));
-    VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
-                       prm->orb.edge_threshold, 1));
     const int n_bound = feat_n_bound(c, prm->orb.nfeatures);
-    VO_TRY(feat_select_dev(c, n_frames, n_bound));
-    VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
+    {
+        ProfScope ps(c, VO_PROF_FEATURES);
+        VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
+                           prm->orb.edge_threshold, 1));
+        VO_TRY(feat_select_dev(c, n_frames, n_bound));
+        VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
+    }
     VO_TRY(pairs_after_selection(c, n_frames, n_bound, K, prm));
     VO_HIP(c, hipMemcpyAsync(c->h_flags.p, c->d_flags.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
                              c->stream));
