@@ -124,16 +124,19 @@ __global__ __launch_bounds__(256) void k_pyr_resize(const PyrGeom* __restrict__ 
 #define SM_H (FT_H + 2)
 #define PX_W (FT_W + 8)
 #define PX_H (FT_H + 8)
+#define FT_LCAP 704  // >= 9 rows x 64 + 68 pixels of phase A per wave, >= 11 x 64 candidates of phase B
 
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
                                                   int threshold, int border, int nms) {
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
     __shared__ __attribute__((aligned(4))) uint8_t sm[SM_H][SM_W + 2];
-    __shared__ uint16_t listA[SM_W * SM_H];
-    __shared__ uint16_t listB[SM_W * SM_H];
+    // survivor / corner lists: one private region per wave (no atomics, no cross-wave ordering
+    // needed: the lists only feed the score map); entries are sy << 7 | sx
+    __shared__ uint16_t listA[4 * FT_LCAP];
+    __shared__ uint16_t listB[4 * FT_LCAP];
     __shared__ uint32_t rowmask[FT_H][2];
-    __shared__ int nA, nB;
+    __shared__ int cntA[4], cntB[4];
     const uint8_t* px = reinterpret_cast<const uint8_t*>(px4);
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0;
@@ -156,20 +159,20 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
     for (int i = tid; i < SM_H * (SM_W + 2) / 4; i += 256) reinterpret_cast<uint32_t*>(&sm[0][0])[i] = 0;
     if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
-    if (tid == 0) {
-        nA = 0;
-        nB = 0;
-    }
     __syncthreads();
 
-    // phase A: compass test
-    for (int p0 = 0; p0 < SM_W * SM_H; p0 += 256) {
-        const int p = p0 + tid;
-        bool surv = false;
-        if (p < SM_W * SM_H) {
-            const int sy = p / SM_W, sx = p - sy * SM_W;
+    const int wv = tid >> 6, lane = tid & 63;
+    const unsigned long long lt = lanemask_lt();
+
+    // phase A: compass test.  Wave w takes the rows w, w + 4, ... of the score region with lane =
+    // column; columns 64 and 65 of all rows are one more step for waves 2 and 3 (they have a row less).
+    {
+        int nloc = 0;
+        uint16_t* mine = listA + wv * FT_LCAP;
+        auto compass = [&](int sy, int sx, bool in) {
+            bool surv = false;
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-            if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+            if (in && x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
                 const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
                 const int v = c[0], lo = v - threshold, hi = v + threshold;
                 const int r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
@@ -178,66 +181,76 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 surv = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) ||
                        (b8 && b12) || (b12 && b0);
             }
+            const unsigned long long m = __ballot(surv);
+            if (surv) mine[nloc + __popcll(m & lt)] = (uint16_t)((sy << 7) | sx);
+            nloc += __popcll(m);
+        };
+        for (int sy = wv; sy < SM_H; sy += 4) compass(sy, lane, true);
+        if (wv >= 2) {
+            const int q = (wv - 2) * 64 + lane;  // 0 .. 2 * SM_H - 1
+            compass(q >> 1, FT_W + (q & 1), q < 2 * SM_H);
         }
-        const unsigned long long m = __ballot(surv);
-        if (m) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&nA, __popcll(m));
-            base = __shfl(base, 0);
-            if (surv) listA[base + __popcll(m & lanemask_lt())] = (uint16_t)p;
-        }
+        if (lane == 0) cntA[wv] = nloc;
     }
     __syncthreads();
 
-    // phase B: full arc test on the survivors
-    const int na = nA;
-    for (int i0 = 0; i0 < na; i0 += 256) {
-        const int i = i0 + tid;
-        bool corner = false;
-        int p = 0;
-        if (i < na) {
-            p = listA[i];
-            const int sy = p / SM_W, sx = p - sy * SM_W;
-            const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-            const int v = c[0], lo = v - threshold, hi = v + threshold;
-            uint32_t dark = 0, bright = 0;
-#define VO_RING(k, dx, dy)                                                      \
-    {                                                                           \
-        const int r = c[(dy) * PX_W + (dx)];                                    \
-        dark |= (uint32_t)(r < lo) << (k);                                      \
-        bright |= (uint32_t)(r > hi) << (k);                                    \
+    // phase B: full arc test on the survivors, dense lanes over the four lists
+    {
+        const int a0 = cntA[0], a1 = a0 + cntA[1], a2 = a1 + cntA[2], na = a2 + cntA[3];
+        int nloc = 0;
+        uint16_t* mine = listB + wv * FT_LCAP;
+        for (int i0 = 0; i0 < na; i0 += 256) {
+            const int i = i0 + tid;
+            bool corner = false;
+            int p = 0;
+            if (i < na) {
+                const int seg = (i >= a0) + (i >= a1) + (i >= a2);
+                p = listA[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? a0 : seg == 2 ? a1 : a2)];
+                const int sy = p >> 7, sx = p & 127;
+                const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+                const int v = c[0], lo = v - threshold, hi = v + threshold;
+                // bit k of dark / bright: ring point k is darker than lo / brighter than hi.  The sign bit
+                // of r - lo (hi - r) is shifted in with one v_alignbit per point, point 15 first.
+                uint32_t dark = 0, bright = 0;
+#define VO_RING(dx, dy)                                                                  \
+    {                                                                                    \
+        const int r = c[(dy) * PX_W + (dx)];                                             \
+        dark = __builtin_amdgcn_alignbit(dark, (uint32_t)(r - lo), 31);                  \
+        bright = __builtin_amdgcn_alignbit(bright, (uint32_t)(hi - r), 31);              \
     }
-            VO_RING(0, 0, 3) VO_RING(1, 1, 3) VO_RING(2, 2, 2) VO_RING(3, 3, 1)
-            VO_RING(4, 3, 0) VO_RING(5, 3, -1) VO_RING(6, 2, -2) VO_RING(7, 1, -3)
-            VO_RING(8, 0, -3) VO_RING(9, -1, -3) VO_RING(10, -2, -2) VO_RING(11, -3, -1)
-            VO_RING(12, -3, 0) VO_RING(13, -3, 1) VO_RING(14, -2, 2) VO_RING(15, -1, 3)
+                VO_RING(-1, 3) VO_RING(-2, 2) VO_RING(-3, 1) VO_RING(-3, 0)
+                VO_RING(-3, -1) VO_RING(-2, -2) VO_RING(-1, -3) VO_RING(0, -3)
+                VO_RING(1, -3) VO_RING(2, -2) VO_RING(3, -1) VO_RING(3, 0)
+                VO_RING(3, 1) VO_RING(2, 2) VO_RING(1, 3) VO_RING(0, 3)
 #undef VO_RING
-            // >= 9 contiguous set bits on the 16-ring
-            const uint32_t xd = dark | (dark << 16), xb = bright | (bright << 16);
-            uint32_t rd = xd & (xd >> 1), rb = xb & (xb >> 1);
-            rd &= rd >> 2;
-            rb &= rb >> 2;
-            rd &= rd >> 4;
-            rb &= rb >> 4;
-            rd &= xd >> 8;
-            rb &= xb >> 8;
-            corner = ((rd | rb) & 0xffffu) != 0;
+                // >= 9 contiguous set bits on the 16-ring
+                const uint32_t xd = dark | (dark << 16), xb = bright | (bright << 16);
+                uint32_t rd = xd & (xd >> 1), rb = xb & (xb >> 1);
+                rd &= rd >> 2;
+                rb &= rb >> 2;
+                rd &= rd >> 4;
+                rb &= rb >> 4;
+                rd &= xd >> 8;
+                rb &= xb >> 8;
+                corner = ((rd | rb) & 0xffffu) != 0;
+            }
+            const unsigned long long m = __ballot(corner);
+            if (corner) mine[nloc + __popcll(m & lt)] = (uint16_t)p;
+            nloc += __popcll(m);
         }
-        const unsigned long long m = __ballot(corner);
-        if (m) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&nB, __popcll(m));
-            base = __shfl(base, 0);
-            if (corner) listB[base + __popcll(m & lanemask_lt())] = (uint16_t)p;
-        }
+        if (lane == 0) cntB[wv] = nloc;
     }
     __syncthreads();
+    const int b0 = cntB[0], b1 = b0 + cntB[1], b2 = b1 + cntB[2], nb = b2 + cntB[3];
+    auto cornerAt = [&](int i) {
+        const int seg = (i >= b0) + (i >= b1) + (i >= b2);
+        return (int)listB[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? b0 : seg == 2 ? b1 : b2)];
+    };
 
     // phase C: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1
-    const int nb = nB;
     for (int i = tid; i < nb; i += 256) {
-        const int p = listB[i];
-        const int sy = p / SM_W, sx = p - sy * SM_W;
+        const int p = cornerAt(i);
+        const int sy = p >> 7, sx = p & 127;
         const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
         const int v = c[0];
         int d[16];
@@ -291,8 +304,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const bool level_ok = border == 0 || (w > 2 * border && h > 2 * border);
     uint8_t* sc = level_px(score, g, f, l);
     for (int i = tid; i < nb; i += 256) {
-        const int p = listB[i];
-        const int sy = p / SM_W, sx = p - sy * SM_W;
+        const int p = cornerAt(i);
+        const int sy = p >> 7, sx = p & 127;
         if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;
         const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
         if (!level_ok || x < b || x >= w - b || y < b || y >= h - b) continue;
