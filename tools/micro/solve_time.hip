@@ -16,6 +16,12 @@ __device__ unsigned long long g_cnt[4];
 #else
 #define FP_COUNT(i)
 #endif
+__device__ int g_stop = 99;
+#define FP_STOP(i, v)            \
+    if (g_stop == (i)) {         \
+        E_out[0] = (v);          \
+        return 1;                \
+    }
 #include "five_point.h"
 
 template <int LANES>
@@ -103,7 +109,15 @@ void run(int nh) {
     hipFree(d_t);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {  // cumulative time up to the end of phase argv[1] (1 null space .. 5 roots, 99 all)
+        for (int stop : {1, 2, 3, 4, 5, 99}) {
+            hipMemcpyToSymbol(HIP_SYMBOL(g_stop), &stop, sizeof(int));
+            printf("== stop after phase %d\n", stop);
+            run<4>(2048);
+        }
+        return 0;
+    }
     run<4>(2048);
     run<64>(2048);
     run<64>(65536);

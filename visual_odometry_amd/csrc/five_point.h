@@ -34,6 +34,10 @@
 #define FP_TICK(i)
 #define FP_COUNT(i)
 #endif
+// early-exit hook of the same tool (cumulative phase timing without code motion across the marks)
+#ifndef FP_STOP
+#define FP_STOP(i, v)
+#endif
 
 namespace fp_detail {
 
@@ -181,6 +185,142 @@ VO_HD int level_roots(const double (&c)[11], double bound, int nprev, const S& s
     return ncur;
 }
 
+// ---- real roots by a Sturm chain ------------------------------------------------------------
+// P0 = c, P1 = c', P(k+1) = -rem(P(k-1), P(k)), every member scaled to max |coefficient| = 1 (positive
+// factors do not change sign counts).  With quotients q_k(x) = a_k x + b_k and g_k = the scale of the
+// remainder, P(k-1)(x) = q_k(x) P(k)(x) - g_k P(k+1)(x): the whole chain is evaluated at a point from
+// its two last members upwards in 3 operations per member, and V(x) = number of sign changes along
+// it.  The number of real roots in (a, b] is V(a) - V(b).  Roots are isolated in ascending order by
+// bisection on t in (-1, 1), x = t / (1 - |t|) (the whole real line, resolution where the roots
+// are), until an interval holds exactly one; that root is then polished on c itself by the
+// safeguarded Newton iteration above.  Every lane does the same few steps per root (little
+// divergence) and a step is ~45 instructions, against ~270 Horner evaluations with data-dependent
+// branching for the derivative chain (145 of the solver's 240 us on MI355X), which stays as the
+// fallback for chains whose degrees do not drop one by one (a vanishing leading coefficient).
+struct SturmChain {
+    double a[9], b[9], g[9];  // step k = index k - 1: quotient and remainder scale of P(k-1) / P(k)
+    double p9[2], p10;        // the last two members, highest coefficient first
+    unsigned neg_pinf, neg_minf;  // bit k: P(k) is negative at +inf / -inf
+};
+
+VO_HD bool sturm_build(const double (&c)[11], SturmChain& ch) {
+    double u[11], v[11];  // P(k-1), P(k), highest coefficient first
+#pragma unroll
+    for (int i = 0; i <= 10; i++) u[i] = c[10 - i];
+    {
+        double m = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            v[i] = u[i] * (double)(10 - i);
+            m = fmax(m, fabs(v[i]));
+        }
+        if (!(m > 0)) return false;
+        const double sc = 1.0 / m;
+#pragma unroll
+        for (int i = 0; i < 10; i++) v[i] *= sc;
+        v[10] = 0;
+    }
+    ch.neg_pinf = (u[0] < 0 ? 1u : 0u) | (v[0] < 0 ? 2u : 0u);
+    ch.neg_minf = (u[0] < 0 ? 1u : 0u) | (v[0] < 0 ? 0u : 2u);  // degree 10 even, degree 9 odd
+#pragma unroll
+    for (int k = 1; k <= 9; k++) {
+        const int d = 10 - k;  // degree of v = P(k); u = P(k-1) has degree d + 1
+        if (!(fabs(v[0]) > 1e-11)) return false;
+        const double inv = 1.0 / v[0];
+        const double qa = u[0] * inv;
+        const double qb = (u[1] - qa * v[1]) * inv;
+        double r[11], m = 0;
+#pragma unroll
+        for (int j = 0; j < d; j++) {  // remainder, degree d - 1 - j
+            const double vj2 = j + 2 <= d ? v[j + 2] : 0.0;
+            r[j] = u[j + 2] - qa * vj2 - qb * v[j + 1];
+            m = fmax(m, fabs(r[j]));
+        }
+        if (!(m > 1e-13)) return false;  // c and c' share a factor: a multiple root
+        const double sc = 1.0 / m;
+        ch.a[k - 1] = qa;
+        ch.b[k - 1] = qb;
+        ch.g[k - 1] = m;
+#pragma unroll
+        for (int j = 0; j <= d; j++) u[j] = v[j];
+#pragma unroll
+        for (int j = 0; j < d; j++) v[j] = -r[j] * sc;
+        v[d] = 0;
+        const bool neg = v[0] < 0;
+        ch.neg_pinf |= neg ? (1u << (k + 1)) : 0u;
+        ch.neg_minf |= (neg != (((d - 1) & 1) != 0)) ? (1u << (k + 1)) : 0u;
+    }
+    ch.p9[0] = u[0];
+    ch.p9[1] = u[1];
+    ch.p10 = v[0];
+    if (!(fabs(ch.p10) > 0)) return false;
+    return true;
+}
+
+VO_HD int sign_changes(unsigned bits) {  // among the 11 chain members
+    return __builtin_popcount((bits ^ (bits >> 1)) & 0x3ffu);
+}
+
+VO_HD int sturm_count(const SturmChain& ch, double x) {
+    double e1 = ch.p10, e0 = fma(ch.p9[0], x, ch.p9[1]);  // P10(x), P9(x)
+    unsigned bits = (e1 < 0 ? (1u << 10) : 0u) | (e0 < 0 ? (1u << 9) : 0u);
+#pragma unroll
+    for (int k = 9; k >= 1; k--) {
+        const double e = fma(fma(ch.a[k - 1], x, ch.b[k - 1]), e0, -(ch.g[k - 1] * e1));  // P(k-1)(x)
+        e1 = e0;
+        e0 = e;
+        bits |= e < 0 ? (1u << (k - 1)) : 0u;
+    }
+    return sign_changes(bits);
+}
+
+// Real roots of c in ascending order into S(out..); -1 if the chain is degenerate.
+template <class S>
+VO_HD int sturm_roots(const double (&c)[11], const S& s, int out) {
+    SturmChain ch;
+    if (!sturm_build(c, ch)) return -1;
+    const int v_minf = sign_changes(ch.neg_minf), v_pinf = sign_changes(ch.neg_pinf);
+    const int total = v_minf - v_pinf;
+    if (total < 0 || total > 10) return -1;
+    int found = 0, n = 0;
+    double ta = -1.0;  // roots up to here are done; V(ta) = va
+    int va = v_minf;
+    while (found < total) {
+        double a = ta, b = 1.0;
+        int ca = va, cb = v_pinf;
+        int step = 0;
+        // the leftmost root of (a, b]: halve towards it until it is alone and the ends are finite
+        while ((ca - cb != 1 || a <= -1.0 || b >= 1.0) && step < 80) {
+            const double m = 0.5 * (a + b);
+            FP_COUNT(1);
+            const int cm = sturm_count(ch, m / (1.0 - fabs(m)));
+            if (ca - cm >= 1) {
+                b = m;
+                cb = cm;
+            } else {
+                a = m;
+                ca = cm;
+            }
+            step++;
+        }
+        const int here = ca - cb;
+        if (here < 1) return -1;  // the counts are not monotone: numerical trouble, use the other finder
+        if (here == 1 && a > -1.0 && b < 1.0) {
+            const double xa = a / (1.0 - fabs(a)), xb = b / (1.0 - fabs(b));
+            double fa, fb, d;
+            horner<10>(c, xa, fa, d);
+            horner<10>(c, xb, fb, d);
+            if ((fa < 0) != (fb < 0)) s(out + n++) = bracket_root<10>(c, xa, xb, fa, 4e-16);
+        }
+        // (a cluster that 80 halvings cannot split is a multiple root without a sign change: skipped,
+        // as the derivative chain skips it)
+        found += here;
+        ta = b;
+        va = cb;
+    }
+    return n;
+}
+
 }  // namespace fp_detail
 
 // x1, x2: five K-normalised correspondences (x, y interleaved), x2^T E x1 = 0.
@@ -279,6 +419,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
         }
     }
     FP_TICK(1);
+    FP_STOP(1, s(200) + s(235));
     // ---- ten cubic constraints -> 10x20 matrix in S (row r at 20 r) -----------------------------
     {
         double e[9][4];  // entry (r,c) of E(x,y,z) = x N0 + y N1 + z N2 + N3
@@ -346,6 +487,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
             }
     }
     FP_TICK(2);
+    FP_STOP(2, s(0) + s(199));
     // ---- Gauss-Jordan on the first ten columns, partial pivoting ---------------------------------
     // Only rows 4..9 of the reduced right-hand block are used afterwards, so finished rows 0..3
     // are not updated any further.
@@ -401,6 +543,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
         }
     }
     FP_TICK(3);
+    FP_STOP(3, s(90) + s(199));
     // ---- B(z): rows e - z f, g - z h, i - z j; coefficients lowest degree first ------------------
     double c[11];
     {
@@ -458,6 +601,7 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
         }
     }
     FP_TICK(4);
+    FP_STOP(4, c[0] + c[10] + c[5]);
     // ---- real roots of c ---------------------------------------------------------------------
     int nroots;
     {
@@ -473,19 +617,27 @@ VO_HD int five_point_solve(const double* x1, const double* x2, const S& s, doubl
         for (int k = 0; k < 10; k++) bmax = fmax(bmax, fabs(c[k]));
         const double bound = 1.0 + bmax / lead;  // Cauchy bound
         if (!(bound < 1e300)) return 0;
-        // roots of successive derivatives; two ping-pong arrays S(0..9) / S(10..19)
-        int n = level_roots<1>(c, bound, 0, s, 10, 0);
-        n = level_roots<2>(c, bound, n, s, 0, 10);
-        n = level_roots<3>(c, bound, n, s, 10, 0);
-        n = level_roots<4>(c, bound, n, s, 0, 10);
-        n = level_roots<5>(c, bound, n, s, 10, 0);
-        n = level_roots<6>(c, bound, n, s, 0, 10);
-        n = level_roots<7>(c, bound, n, s, 10, 0);
-        n = level_roots<8>(c, bound, n, s, 0, 10);
-        n = level_roots<9>(c, bound, n, s, 10, 0);
-        nroots = level_roots<10>(c, bound, n, s, 0, 10);  // roots at S(10..)
+#ifdef FP_NO_STURM  // test builds: the derivative chain alone, to compare the two finders
+        nroots = -1;
+#else
+        nroots = sturm_roots(c, s, 10);  // roots at S(10..)
+#endif
+        if (nroots < 0) {
+            // roots of successive derivatives; two ping-pong arrays S(0..9) / S(10..19)
+            int n = level_roots<1>(c, bound, 0, s, 10, 0);
+            n = level_roots<2>(c, bound, n, s, 0, 10);
+            n = level_roots<3>(c, bound, n, s, 10, 0);
+            n = level_roots<4>(c, bound, n, s, 0, 10);
+            n = level_roots<5>(c, bound, n, s, 10, 0);
+            n = level_roots<6>(c, bound, n, s, 0, 10);
+            n = level_roots<7>(c, bound, n, s, 10, 0);
+            n = level_roots<8>(c, bound, n, s, 0, 10);
+            n = level_roots<9>(c, bound, n, s, 10, 0);
+            nroots = level_roots<10>(c, bound, n, s, 0, 10);  // roots at S(10..)
+        }
     }
     FP_TICK(5);
+    FP_STOP(5, (double)nroots + s(10));
     // ---- back-substitution ---------------------------------------------------------------------
     int count = 0;
     for (int i = 0; i < nroots; i++) {
