@@ -448,22 +448,49 @@ __global__ __launch_bounds__(256) void k_cand_write(const PyrGeom* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // Harris response (7x7 block, k = 0.04f) in cv's float evaluation order.
 // ---------------------------------------------------------------------------------------------
+// The 9 x 9 patch is read as nine rows of three aligned dwords (27 loads instead of 392 byte
+// loads) and walked with three rows in registers: S = up + 2 mid + down and D = down - up per column,
+// Ix = S[j+1] - S[j-1], Iy = D[j-1] + 2 D[j] + D[j+1]: the same integers as cv's per-pixel Sobel sums.
 __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
-    const int blockSize = 7, r = 3;
     const float harris_k = 0.04f;
-    const float scale = 1.f / ((1 << 2) * blockSize * 255.f);
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
-    const uint8_t* p00 = img + (ptrdiff_t)(y0 - r) * pitch + (x0 - r);
+    const int xs = x0 - 4, o = xs & 3;
+    const uint8_t* base = img + (ptrdiff_t)(y0 - 4) * pitch + (xs - o);
+    int R[3][9];
     int a = 0, b = 0, c = 0;
-    for (int i = 0; i < blockSize; i++)
-        for (int j = 0; j < blockSize; j++) {
-            const uint8_t* p = p00 + i * pitch + j;
-            int Ix = (p[1] - p[-1]) * 2 + (p[-pitch + 1] - p[-pitch - 1]) + (p[pitch + 1] - p[pitch - 1]);
-            int Iy = (p[pitch] - p[-pitch]) * 2 + (p[pitch - 1] - p[-pitch - 1]) + (p[pitch + 1] - p[-pitch + 1]);
-            a += Ix * Ix;
-            b += Iy * Iy;
-            c += Ix * Iy;
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)r * pitch);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, o), w1 = __builtin_amdgcn_alignbyte(d2, d1, o),
+                       w2 = __builtin_amdgcn_alignbyte(0u, d2, o);
+        int* row = R[r % 3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            row[k] = (w0 >> (8 * k)) & 0xff;
+            row[4 + k] = (w1 >> (8 * k)) & 0xff;
         }
+        row[8] = w2 & 0xff;
+        if (r >= 2) {
+            const int* up = R[(r - 2) % 3];
+            const int* mid = R[(r - 1) % 3];
+            int S[9], D[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                S[k] = up[k] + 2 * mid[k] + row[k];
+                D[k] = row[k] - up[k];
+            }
+#pragma unroll
+            for (int j = 1; j <= 7; j++) {
+                const int Ix = S[j + 1] - S[j - 1];
+                const int Iy = D[j - 1] + 2 * D[j] + D[j + 1];
+                a += Ix * Ix;
+                b += Iy * Iy;
+                c += Ix * Iy;
+            }
+        }
+    }
     const float fa = (float)a, fb = (float)b, fc = (float)c;
     return (fa * fb - fc * fc - harris_k * (fa + fb) * (fa + fb)) * scale_sq_sq;
 }
