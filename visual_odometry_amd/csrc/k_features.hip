@@ -518,8 +518,8 @@ __global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ pyr,
 // "before" the pivot, the j-th stop of the right pointer the j-th from the right that is not
 // "after" it, and the pointers swap exactly while left stop < right stop — so one wavefront finds
 // both stop lists with ballots, counts the swaps and performs them at once.
-// One block per (frame, level): wave 0 runs the selection on the list held in LDS, all waves
-// compute the Harris responses in between.  The depth-limit (heap-select) branch of introselect and
+// One block per (frame, level): its four waves share every partition round of the selection on the
+// list held in LDS and compute the Harris responses in between.  The depth-limit (heap-select) branch of introselect and
 // lists larger than the LDS buffer are flagged and redone by the host path.
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -529,20 +529,21 @@ struct RI {
     int idx;
 };
 
-__device__ __forceinline__ void lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // MODE 0: std::__unguarded_partition(first, last, pivot) with comp(a, b) = a.r > b.r; returns cut.
 // MODE 1: std::__partition(first, last, pred) with pred(a) = a.r >= key; returns the new end.
+// All 256 threads call it with the same arguments.  Each wave lists the stops of its quarter of the
+// range in its own segment of Lp / Ra; the j-th stop overall is found through the four segment counts
+// (sh[0..7]), so the lists are never compacted.
 template <int MODE>
-__device__ int wave_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int lane) {
+__device__ int block_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int* sh, int tid) {
+    const int wv = tid >> 6, lane = tid & 63;
+    const int span = ((last - first + 255) >> 8) << 6;
+    const int wb = first + wv * span, we = min(last, wb + span);
     int nL = 0, nR = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int i0 = first; i0 < last; i0 += 64) {
+    for (int i0 = wb; i0 < we; i0 += 64) {
         const int i = i0 + lane;
-        const bool in = i < last;
+        const bool in = i < we;
         const float r = in ? v[i].r : 0.f;
         bool isL, isR;
         if (MODE == 0) {
@@ -553,43 +554,60 @@ __device__ int wave_partition(RI* v, int first, int last, float key, uint16_t* L
             isL = in && !(r >= key);  // the left pointer stops on !pred
         }
         const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-        if (isL) Lp[nL + __popcll(bL & lt)] = (uint16_t)i;
-        if (isR) Ra[nR + __popcll(bR & lt)] = (uint16_t)i;
+        if (isL) Lp[wb + nL + __popcll(bL & lt)] = (uint16_t)i;
+        if (isR) Ra[wb + nR + __popcll(bR & lt)] = (uint16_t)i;
         nL += __popcll(bL);
         nR += __popcll(bR);
     }
-    lds_fence();
-    const int m = min(nL, nR);
-    int K = 0;  // number of swaps: stops cross monotonically
-    for (int k0 = 0; k0 < m; k0 += 64) {
-        const int k = k0 + lane;
-        const bool ok = k < m && Lp[k] < Ra[nR - 1 - k];
-        K += __popcll(__ballot(ok));
+    if (lane == 0) {
+        sh[wv] = nL;
+        sh[4 + wv] = nR;
     }
+    __syncthreads();
+    const int l0 = sh[0], l1 = l0 + sh[1], l2 = l1 + sh[2], nLt = l2 + sh[3];
+    const int r0 = sh[4], r1 = r0 + sh[5], r2 = r1 + sh[6], nRt = r2 + sh[7];
+    auto leftStop = [&](int k) -> int {  // k-th stop of the left pointer
+        const int w = (k >= l0) + (k >= l1) + (k >= l2);
+        const int pre = w == 0 ? 0 : w == 1 ? l0 : w == 2 ? l1 : l2;
+        return Lp[first + w * span + (k - pre)];
+    };
+    auto rightStop = [&](int k) -> int {  // k-th stop of the right pointer (counted from the right)
+        const int q = nRt - 1 - k;
+        const int w = (q >= r0) + (q >= r1) + (q >= r2);
+        const int pre = w == 0 ? 0 : w == 1 ? r0 : w == 2 ? r1 : r2;
+        return Ra[first + w * span + (q - pre)];
+    };
+    const int m = min(nLt, nRt);
+    int Kw = 0;  // number of swaps: stops cross monotonically
+    for (int k0 = 0; k0 < m; k0 += 256) {
+        const int k = k0 + tid;
+        const bool ok = k < m && leftStop(k) < rightStop(k);
+        Kw += __popcll(__ballot(ok));
+    }
+    if (lane == 0) sh[8 + wv] = Kw;
+    __syncthreads();
+    const int K = sh[8] + sh[9] + sh[10] + sh[11];
     int ret;
     if (MODE == 0) {
-        const int a = K < nL ? (int)Lp[K] : last;
-        const int b = K > 0 ? (int)Ra[nR - K] : last;
+        const int a = K < nLt ? leftStop(K) : last;
+        const int b = K > 0 ? rightStop(K - 1) : last;
         ret = min(a, b);
     } else {
-        ret = first + nR;
+        ret = first + nRt;
     }
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        if (k < K) {
-            const int a = Lp[k], b = Ra[nR - 1 - k];
-            const RI t = v[a];
-            v[a] = v[b];
-            v[b] = t;
-        }
+    for (int k = tid; k < K; k += 256) {
+        const int a = leftStop(k), b = rightStop(k);
+        const RI t = v[a];
+        v[a] = v[b];
+        v[b] = t;
     }
-    lds_fence();
+    __syncthreads();
     return ret;
 }
 
 // std::nth_element(v + first, v + nth, v + last, greater-by-response); false when libstdc++ would
-// enter its heap-select fallback (depth limit reached).
-__device__ bool wave_nth_element(RI* v, int first, int nth, int last, uint16_t* Lp, uint16_t* Ra, int lane) {
+// enter its heap-select fallback (depth limit reached).  Called by the whole block.
+__device__ bool block_nth_element(RI* v, int first, int nth, int last, uint16_t* Lp, uint16_t* Ra, int* sh, int tid) {
     if (first == last || nth == last) return true;
     int depth = 2 * (31 - __clz(last - first));
     while (last - first > 3) {
@@ -605,20 +623,20 @@ __device__ bool wave_nth_element(RI* v, int first, int nth, int last, uint16_t* 
         } else if (ra > rc) sel = first + 1;
         else if (rb > rc) sel = last - 1;
         else sel = mid;
-        lds_fence();
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             const RI t = v[first];
             v[first] = v[sel];
             v[sel] = t;
         }
-        lds_fence();
+        __syncthreads();
         const float pivot = v[first].r;
-        const int cut = wave_partition<0>(v, first + 1, last, pivot, Lp, Ra, lane);
+        const int cut = block_partition<0>(v, first + 1, last, pivot, Lp, Ra, sh, tid);
         if (cut <= nth) first = cut;
         else last = cut;
     }
     // std::__insertion_sort on the remaining <= 3 elements
-    if (lane == 0) {
+    if (tid == 0) {
         for (int i = first + 1; i < last; i++) {
             const RI val = v[i];
             if (val.r > v[first].r) {
@@ -634,17 +652,17 @@ __device__ bool wave_nth_element(RI* v, int first, int nth, int last, uint16_t* 
             }
         }
     }
-    lds_fence();
+    __syncthreads();
     return true;
 }
 
 // KeyPointsFilter::retainBest; returns the new size, -1 on the depth-limit fallback
-__device__ int wave_retain_best(RI* v, int n, int n_points, uint16_t* Lp, uint16_t* Ra, int lane) {
+__device__ int block_retain_best(RI* v, int n, int n_points, uint16_t* Lp, uint16_t* Ra, int* sh, int tid) {
     if (n_points < 0 || n <= n_points) return n;
     if (n_points == 0) return 0;
-    if (!wave_nth_element(v, 0, n_points, n, Lp, Ra, lane)) return -1;
+    if (!block_nth_element(v, 0, n_points, n, Lp, Ra, sh, tid)) return -1;
     const float ambiguous = v[n_points - 1].r;
-    return wave_partition<1>(v, n_points, n, ambiguous, Lp, Ra, lane);
+    return block_partition<1>(v, n_points, n, ambiguous, Lp, Ra, sh, tid);
 }
 
 }  // namespace
@@ -655,12 +673,11 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
                                                     int* __restrict__ selidx, int* __restrict__ selcnt,
                                                     int* __restrict__ flags) {
     extern __shared__ unsigned char sel_smem[];
-    __shared__ int s_n;
+    __shared__ int sh[12];
     RI* v = reinterpret_cast<RI*>(sel_smem);
     uint16_t* Lp = reinterpret_cast<uint16_t*>(v + sel_cap);
     uint16_t* Ra = Lp + sel_cap;
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const bool w0 = tid < 64;
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const int b = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l], max_cand);
     const int e = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l + 1], max_cand);
     int n = e - b;
@@ -680,12 +697,7 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         v[i] = t;
     }
     __syncthreads();
-    if (w0) {
-        const int r = wave_retain_best(v, n, 2 * quota.q[l], Lp, Ra, lane);
-        if (lane == 0) s_n = r;
-    }
-    __syncthreads();
-    n = s_n;
+    n = block_retain_best(v, n, 2 * quota.q[l], Lp, Ra, sh, tid);
     if (n < 0) {
         if (tid == 0) {
             atomicOr(&flags[f], VO_SEL_DEPTH);
@@ -702,12 +714,7 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         v[i].r = hr;
     }
     __syncthreads();
-    if (w0) {
-        const int r = wave_retain_best(v, n, quota.q[l], Lp, Ra, lane);
-        if (lane == 0) s_n = r;
-    }
-    __syncthreads();
-    n = s_n;
+    n = block_retain_best(v, n, quota.q[l], Lp, Ra, sh, tid);
     if (n < 0) {
         if (tid == 0) {
             atomicOr(&flags[f], VO_SEL_DEPTH);
