@@ -776,52 +776,76 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
                                                   const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
-    __shared__ int8_t s_umax[16];
-    if (threadIdx.x < 16) {
-        const int8_t um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-        s_umax[threadIdx.x] = um[threadIdx.x];
-    }
-    __syncthreads();
+    // half-width of the disc per |row|: {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}, one nibble each
+    const unsigned long long umax_nibbles = 0x3689abcddeeeffffull;
     const int f = blockIdx.y;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (k >= nkp[f]) return;
+    // Few dependent loads: the per-level counts and offsets of the frame arrive together (uniform
+    // addresses), the level's geometry is fetched while the selidx -> cand chain is in flight.
     Cand cd;
+    int lg;
     if (sel) {
         cd = sel[(size_t)f * kp_cap + k];
+        lg = cd.level;
     } else {
-        int l = 0, rem = k;
-        for (; l < g->nlevels; l++) {
-            const int c = selcnt[(size_t)f * VO_ORB_MAX_LEVELS + l];
-            if (rem < c) break;
-            rem -= c;
+        const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
+        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
+        int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+            cnt[i] = sc[i];
+            ofs[i] = lo[i];
         }
-        const int idx = selidx[(size_t)f * max_cand + lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l] + rem];
+        const int nl = g->nlevels;
+        int l = nl, rem = k, base = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++)
+            if (!found && i < nl) {
+                if (rem < cnt[i]) {
+                    found = true;
+                    l = i;
+                    base = ofs[i];
+                } else {
+                    rem -= cnt[i];
+                }
+            }
+        if (!found) return;  // k < nkp = sum of the counts: not reached
+        lg = __builtin_amdgcn_readfirstlane(l);
+        const int idx = selidx[(size_t)f * max_cand + base + rem];
         cd = cand[(size_t)f * max_cand + idx];
     }
-    const int pitch = g->lv[cd.level].pitch;
+    const int pitch = g->lv[lg].pitch;
+    const float lscale = g->lv[lg].scale;
     // The 31 x 31 patch is read as 31 rows x 9 aligned dwords (279 work items over the wave); a work
     // item masks the bytes outside the disc and takes sum(b) and sum(j b) with two v_dot4_u32_u8:
     // sum(u b) = u(first byte) sum(b) + sum(j b).  Integer sums: the same m10, m01 as a per-pixel loop.
     const int xw = (cd.x - 15) & ~3, o = (cd.x - 15) - xw;
-    const uint8_t* base = level_px(pyr, g, f, cd.level) + (ptrdiff_t)cd.y * pitch + xw;
+    const uint8_t* base = level_px(pyr, g, f, lg) + (ptrdiff_t)cd.y * pitch + xw;
     int m01 = 0, m10 = 0;
+    uint32_t dw[5];  // all five loads are issued before the first is used
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-        const int item = lane + 64 * j;
-        if (item < 31 * 9) {
-            const int row = item / 9, k = item - row * 9;
-            const int v = row - 15, um = s_umax[v < 0 ? -v : v];
-            const int u0 = 4 * k - 15 - o;             // u of byte 0 of this dword
-            const int jlo = max(-um - u0, 0), jhi = min(um - u0, 3);
-            if (jlo <= jhi) {
-                const uint32_t mask = (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (3 - jhi)));
-                const uint32_t d = *reinterpret_cast<const uint32_t*>(base + v * pitch + 4 * k) & mask;
-                const int sb = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
-                const int sj = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
-                m10 += u0 * sb + sj;
-                m01 += v * sb;
-            }
+        const int item = min(lane + 64 * j, 31 * 9 - 1);
+        const int row = item / 9, k = item - row * 9;
+        dw[j] = *reinterpret_cast<const uint32_t*>(base + (row - 15) * pitch + 4 * k);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int item = min(lane + 64 * j, 31 * 9 - 1);
+        const int row = item / 9, k = item - row * 9;
+        const int v = row - 15, um = (int)(umax_nibbles >> (4 * (v < 0 ? -v : v))) & 15;
+        const int u0 = 4 * k - 15 - o;             // u of byte 0 of this dword
+        const int jlo = max(-um - u0, 0), jhi = min(um - u0, 3);
+        if (jlo <= jhi && lane + 64 * j < 31 * 9) {
+            const uint32_t mask = (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (3 - jhi)));
+            const uint32_t d = dw[j] & mask;
+            const int sb = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
+            const int sj = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
+            m10 += u0 * sb + sj;
+            m01 += v * sb;
         }
     }
 #pragma unroll
@@ -830,7 +854,7 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
         m01 += __shfl_xor(m01, o2);
     }
     if (lane == 0) {
-        const float s = g->lv[cd.level].scale;
+        const float s = lscale;
         vo_keypoint kp;
         kp.x = (float)cd.x * s;
         kp.y = (float)cd.y * s;
@@ -926,42 +950,94 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
 
 // ---------------------------------------------------------------------------------------------
 // rBRIEF-256 (WTA_K = 2): 32 lanes per keypoint, lane b computes descriptor byte b (16 rotated
-// pattern points).  cos/sin are taken in double and rounded to float, as cv does.
+// pattern points).  cos/sin are taken in double and rounded to float, as cv does (once per keypoint,
+// by the first lanes of the block).  The rotated pattern stays within 18 pixels of the centre
+// (largest pattern norm 18.4), so the 37 x 37 window is first copied to LDS with aligned dword loads,
+// three rows of ten dwords per step, and the 512 scattered byte reads per keypoint go to LDS.
 // ---------------------------------------------------------------------------------------------
-__constant__ int8_t c_orb_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[1024] = {
 #include "orb_pattern.inc"
 };
+
+#define RB_R 18
+#define RB_ROWS (2 * RB_R + 1)
+#define RB_DW 10  // dwords per window row: 37 bytes at any byte offset 0..3
+#define RB_KP 8   // keypoints per block
 
 __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, const uint8_t* __restrict__ blur,
                                                 const vo_keypoint* __restrict__ kps, const int* __restrict__ nkp,
                                                 int kp_cap, uint8_t* __restrict__ desc) {
-    __shared__ int8_t pat[1024];
-    for (int i = threadIdx.x; i < 1024; i += 256) pat[i] = c_orb_pattern[i];
+    __shared__ __attribute__((aligned(16))) float patf[1024];
+    __shared__ uint32_t win[RB_KP][RB_ROWS * RB_DW];
+    __shared__ float s_ca[RB_KP], s_sa[RB_KP];
+    __shared__ PyrGeom s_g;
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int k0 = blockIdx.x * RB_KP, n = nkp[f];
+    if (k0 >= n) return;
+    // Loads that depend on nothing else go out together: geometry, pattern, the slot's keypoint and (first
+    // lanes) the angles; the window loads follow in one batch after the first barrier.
+    const int slot = tid >> 5, b = tid & 31, k = k0 + slot;
+    const bool live = k < n;
+    const vo_keypoint kp = kps[(size_t)f * kp_cap + min(k, n - 1)];
+    float angle = kps[(size_t)f * kp_cap + min(k0 + (tid & (RB_KP - 1)), n - 1)].angle;
+    static_assert(sizeof(PyrGeom) % 4 == 0 && sizeof(PyrGeom) / 4 <= 256, "geometry copied by one pass");
+    constexpr int GEOM_DW = (int)(sizeof(PyrGeom) / 4);
+    const uint32_t gdw = reinterpret_cast<const uint32_t*>(g)[min(tid, GEOM_DW - 1)];
+    const uint32_t q = reinterpret_cast<const uint32_t*>(c_orb_pattern)[tid];
+    if (tid < GEOM_DW) reinterpret_cast<uint32_t*>(&s_g)[tid] = gdw;
+    {
+        float4 v;
+        v.x = (float)(int8_t)(q & 0xff);
+        v.y = (float)(int8_t)((q >> 8) & 0xff);
+        v.z = (float)(int8_t)((q >> 16) & 0xff);
+        v.w = (float)(int8_t)(q >> 24);
+        reinterpret_cast<float4*>(patf)[tid] = v;
+    }
     __syncthreads();
-    const int f = blockIdx.y;
-    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int b = threadIdx.x & 31;
-    if (k >= nkp[f]) return;
-    const vo_keypoint kp = kps[(size_t)f * kp_cap + k];
     const int l = kp.octave;
-    const int pitch = g->lv[l].pitch;
-    const float scale = 1.f / g->lv[l].scale;
-    float angle = kp.angle;
-    angle *= (float)(3.14159265358979323846 / 180.f);
-    const float ca = (float)cos((double)angle), sa = (float)sin((double)angle);
+    const int pitch = s_g.lv[l].pitch, h = s_g.lv[l].h;
+    const float scale = 1.f / s_g.lv[l].scale;
     const int cy = __float2int_rn(kp.y * scale), cx = __float2int_rn(kp.x * scale);
-    const uint8_t* center = level_px(blur, g, f, l) + (ptrdiff_t)cy * pitch + cx;
-    const int8_t* p = pat + b * 32;
+    const int xw = (cx - RB_R) & ~3, o = cx - RB_R - xw;
+    const bool stage = live && b < 3 * RB_DW;
+    const int r = b / RB_DW, c = b - r * RB_DW;
+    // clamped to the level's padded frame: a window that leaves it (edge threshold < 19) reads defined
+    // memory; inside the frame the clamps change nothing
+    const int gx = min(max(xw + 4 * c, -VO_PADX), pitch - VO_PADX - 4);
+    const uint8_t* col = blur + (size_t)f * s_g.pyr_bytes + s_g.lv[l].offset + (size_t)VO_PADY * pitch + VO_PADX + gx;
+    uint32_t wd[(RB_ROWS + 2) / 3];
+#pragma unroll
+    for (int i = 0; i < (RB_ROWS + 2) / 3; i++) {
+        const int row = r + 3 * i;
+        const int gy = min(max(cy - RB_R + row, -VO_PADY), h + VO_PADY - 1);
+        wd[i] = 0;
+        if (stage && row < RB_ROWS) wd[i] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch);
+    }
+    if (tid < RB_KP) {  // overlaps the window loads
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        s_ca[tid] = (float)cos((double)angle);
+        s_sa[tid] = (float)sin((double)angle);
+    }
+#pragma unroll
+    for (int i = 0; i < (RB_ROWS + 2) / 3; i++) {
+        const int row = r + 3 * i;
+        if (stage && row < RB_ROWS) win[slot][row * RB_DW + c] = wd[i];
+    }
+    __syncthreads();
+    if (!live) return;
+    const float ca = s_ca[slot], sa = s_sa[slot];
+    const uint8_t* center = reinterpret_cast<const uint8_t*>(win[slot]) + RB_R * (4 * RB_DW) + RB_R + o;
+    const float2* p = reinterpret_cast<const float2*>(patf) + b * 16;
     int val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         int v[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float px = (float)p[(2 * t + e) * 2], py = (float)p[(2 * t + e) * 2 + 1];
-            const float x = px * ca - py * sa;
-            const float y = px * sa + py * ca;
-            v[e] = center[__float2int_rn(y) * pitch + __float2int_rn(x)];
+            const float2 pt = p[2 * t + e];
+            const float x = pt.x * ca - pt.y * sa;
+            const float y = pt.x * sa + pt.y * ca;
+            v[e] = center[__float2int_rn(y) * (4 * RB_DW) + __float2int_rn(x)];
         }
         val |= (v[0] < v[1]) << t;
     }
