@@ -17,6 +17,14 @@ __device__ __forceinline__ uint8_t* level_px(uint8_t* buf, const PyrGeom* g, int
     return buf + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)VO_PADY * g->lv[l].pitch + VO_PADX;
 }
 
+// Pins a loaded value at this point of the program: without it the compiler sinks a load whose only
+// use is conditional into the branch, which turns a batch of independent loads into a chain of
+// load -> wait -> load.
+template <class T>
+__device__ __forceinline__ void pin_loaded(T& v) {
+    asm volatile("" : "+v"(v));
+}
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
@@ -150,11 +158,22 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const uint8_t* img = level_px(pyr, g, f, l);
 
     // phase 0
-    for (int i = tid; i < PX_H * (PX_W / 4); i += 256) {
-        const int r = i / (PX_W / 4), c4 = i - r * (PX_W / 4);
-        const int gy = min(max(ty0 - 4 + r, -VO_PADY), h + VO_PADY - 1);
-        const int gx = min(max(tx0 - 4 + 4 * c4, -VO_PADX), pitch - VO_PADX - 4);
-        px4[i] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
+    {
+        constexpr int N0 = PX_H * (PX_W / 4), STEPS = (N0 + 255) / 256;
+        uint32_t d[STEPS];  // all loads of the thread in flight together
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int i = min(tid + 256 * s, N0 - 1);
+            const int r = i / (PX_W / 4), c4 = i - r * (PX_W / 4);
+            const int gy = min(max(ty0 - 4 + r, -VO_PADY), h + VO_PADY - 1);
+            const int gx = min(max(tx0 - 4 + 4 * c4, -VO_PADX), pitch - VO_PADX - 4);
+            d[s] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) pin_loaded(d[s]);
+#pragma unroll
+        for (int s = 0; s < STEPS; s++)
+            if (tid + 256 * s < N0) px4[tid + 256 * s] = d[s];
     }
     static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
     for (int i = tid; i < SM_H * (SM_W + 2) / 4; i += 256) reinterpret_cast<uint32_t*>(&sm[0][0])[i] = 0;
@@ -358,53 +377,111 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
     const unsigned long long* M = masks + (size_t)f * total;
     int* SB = segbase + (size_t)f * total;
     // a lane owns eight consecutive words (64 bytes) per step of 512: serial prefix inside the lane,
-    // one wave scan per step
-    int sum = 0;
-    for (int i0 = beg; i0 < end; i0 += 512) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + 8 * lane + u;
-            sum += i < end ? __popcll(M[i]) : 0;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) wtot[wv] = sum;
-    __syncthreads();
-    int run = 0;
-    for (int k = 0; k < wv; k++) run += wtot[k];
-    int seg0[VO_ORB_MAX_LEVELS];  // level starts, in registers for the loop below
+    // one wave scan per step.  Up to RS_STEPS steps per wave (the usual geometry needs three) are read
+    // once, every load in flight together, and their popcounts stay in registers for the second pass;
+    // the table is padded (VO_MASK_PAD words) so these loads need no bounds.
+    int seg0[VO_ORB_MAX_LEVELS];  // level starts, in registers for the loops below
 #pragma unroll
     for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) seg0[l] = l < nlevels ? g->lv[l].seg0 : -1;
-    for (int i0 = beg; i0 < end; i0 += 512) {
-        const int ib = i0 + 8 * lane;
-        int c[8], t = 0;
+    constexpr int RS_STEPS = 4;
+    static_assert((RS_STEPS + 15) * 512 <= VO_MASK_PAD, "the last wave starts at most 15 * 512 words past the table end");
+    if (per <= RS_STEPS * 512) {
+        int c[RS_STEPS][8], t[RS_STEPS];
+        int sum = 0;
+        {
+            unsigned long long m[RS_STEPS][8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            c[u] = ib + u < end ? __popcll(M[ib + u]) : 0;
-            t += c[u];
-        }
-        int inc = t;
+            for (int s = 0; s < RS_STEPS; s++)
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
-        int base = run + inc - t;
+                for (int u = 0; u < 8; u++) m[s][u] = M[beg + 512 * s + 8 * lane + u];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = ib + u;
-            if (i < end) {
-                SB[i] = base;
+            for (int s = 0; s < RS_STEPS; s++) {
+                const int ib = beg + 512 * s + 8 * lane;
+                t[s] = 0;
 #pragma unroll
-                for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
-                    if (i == seg0[l]) lvl[l] = base;
+                for (int u = 0; u < 8; u++) {
+                    pin_loaded(m[s][u]);
+                    c[s][u] = ib + u < end ? __popcll(m[s][u]) : 0;
+                    t[s] += c[s][u];
+                }
+                sum += t[s];
             }
-            base += c[u];
         }
-        run += __shfl(inc, 63);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) wtot[wv] = sum;
+        __syncthreads();
+        int run = 0;
+        for (int k = 0; k < wv; k++) run += wtot[k];
+#pragma unroll
+        for (int s = 0; s < RS_STEPS; s++) {
+            const int ib = beg + 512 * s + 8 * lane;
+            int inc = t[s];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
+            int base = run + inc - t[s];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = ib + u;
+                if (i < end) {
+                    SB[i] = base;
+#pragma unroll
+                    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
+                        if (i == seg0[l]) lvl[l] = base;
+                }
+                base += c[s][u];
+            }
+            run += __shfl(inc, 63);
+        }
+        if (wv == 15 && lane == 0) lvl[nlevels] = run;
+    } else {
+        int sum = 0;
+        for (int i0 = beg; i0 < end; i0 += 512) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 8 * lane + u;
+                sum += i < end ? __popcll(M[i]) : 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) wtot[wv] = sum;
+        __syncthreads();
+        int run = 0;
+        for (int k = 0; k < wv; k++) run += wtot[k];
+        for (int i0 = beg; i0 < end; i0 += 512) {
+            const int ib = i0 + 8 * lane;
+            int c[8], t = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                c[u] = ib + u < end ? __popcll(M[ib + u]) : 0;
+                t += c[u];
+            }
+            int inc = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
+            int base = run + inc - t;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = ib + u;
+                if (i < end) {
+                    SB[i] = base;
+#pragma unroll
+                    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
+                        if (i == seg0[l]) lvl[l] = base;
+                }
+                base += c[u];
+            }
+            run += __shfl(inc, 63);
+        }
+        if (wv == 15 && lane == 0) lvl[nlevels] = run;
     }
-    if (wv == 15 && lane == 0) lvl[nlevels] = run;
     __syncthreads();
     if ((int)threadIdx.x <= nlevels) lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] = lvl[threadIdx.x];
 }
@@ -419,6 +496,7 @@ __global__ __launch_bounds__(256) void k_cand_write(const PyrGeom* __restrict__ 
     const int sg = blockIdx.x * 256 + threadIdx.x;
     if (sg >= g->segs_total) return;
     unsigned long long m = masks[(size_t)f * g->segs_total + sg];
+    int pos = segbase[(size_t)f * g->segs_total + sg];  // with the mask load, not after it
     if (!m) return;
     int l = 0;
     for (int k = 1; k < g->nlevels; k++)
@@ -426,7 +504,6 @@ __global__ __launch_bounds__(256) void k_cand_write(const PyrGeom* __restrict__ 
     const int local = sg - g->lv[l].seg0;
     const int y = local / g->lv[l].segs, sx = local - y * g->lv[l].segs;
     const uint8_t* sc = level_px(score, g, f, l) + (size_t)y * g->lv[l].pitch;
-    int pos = segbase[(size_t)f * g->segs_total + sg];
     while (m) {
         const int bit = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -690,11 +767,22 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         return;
     }
     Cand* C = cand + (size_t)f * max_cand;
-    for (int i = tid; i < n; i += 256) {
-        RI t;
-        t.r = (float)C[b + i].score;
-        t.idx = b + i;
-        v[i] = t;
+    for (int i0 = 0; i0 < n; i0 += 1024) {  // four loads in flight per thread
+        int sc4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sc4[u] = C[b + min(i0 + 256 * u + tid, n - 1)].score;
+#pragma unroll
+        for (int u = 0; u < 4; u++) pin_loaded(sc4[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 256 * u + tid;
+            if (i < n) {
+                RI t;
+                t.r = (float)sc4[u];
+                t.idx = b + i;
+                v[i] = t;
+            }
+        }
     }
     __syncthreads();
     n = block_retain_best(v, n, 2 * quota.q[l], Lp, Ra, sh, tid);

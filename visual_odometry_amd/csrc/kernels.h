@@ -67,6 +67,9 @@ struct GaussGrid {
 };
 
 // candidate corner / selected keypoint in level coordinates (16 bytes)
+// words of slack after the last frame's mask table: k_row_scan reads whole 512-word steps
+#define VO_MASK_PAD (20 * 512)
+
 struct Cand {
     int16_t x, y;
     int16_t level;

@@ -211,7 +211,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     VO_TRY(vo_ensure(c, c->d_pyr, nf * c->geom.pyr_bytes));
     VO_TRY(vo_ensure(c, c->d_blur, nf * c->geom.pyr_bytes));
     VO_TRY(vo_ensure(c, c->d_score, nf * c->geom.pyr_bytes));
-    VO_TRY(vo_ensure(c, c->d_masks, nf * c->geom.segs_total * sizeof(unsigned long long)));
+    VO_TRY(vo_ensure(c, c->d_masks, (nf * c->geom.segs_total + VO_MASK_PAD) * sizeof(unsigned long long)));
     VO_TRY(vo_ensure(c, c->d_segbase, nf * c->geom.segs_total * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
