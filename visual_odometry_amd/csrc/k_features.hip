@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
     if (x4 >= w + 3 || y >= h + 3) return;
     const uint8_t* src = img + (size_t)f * frame_stride + (size_t)reflect101(y, h) * stride;
     uint32_t v = 0;
+    if (x4 >= 0 && x4 + 3 < w) {
+        __builtin_memcpy(&v, src + x4, 4);  // one unaligned dword load (caller rows have any alignment)
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) v |= (uint32_t)src[reflect101(x4 + j, w)] << (8 * j);
+        for (int j = 0; j < 4; j++) v |= (uint32_t)src[reflect101(x4 + j, w)] << (8 * j);
+    }
     uint8_t* dst = level_px(pyr, g, f, 0);
     *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * pitch + x4) = v;
 }
@@ -65,36 +69,60 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // coordinate) is staged in LDS with aligned dword loads, then every thread makes four pixels of two
 // rows from LDS bytes and stores aligned dwords.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyr_resize(const PyrGeom* __restrict__ g, uint8_t* __restrict__ pyr,
-                                                    int level, const uint32_t* __restrict__ xtab,
-                                                    const uint32_t* __restrict__ ytab, int ldw) {
+struct ResizeArgs {  // geometry of the two levels, from the host copy: nothing to fetch before the tables
+    int dw, dh, dpitch, sw, sh, spitch;
+    unsigned soff, doff, pyr_bytes;  // level offsets include the padding rows and columns
+    int ldw;
+};
+
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, ResizeArgs a,
+                                                    const uint32_t* __restrict__ xtab,
+                                                    const uint32_t* __restrict__ ytab) {
     extern __shared__ uint32_t rs_tile[];
     const int f = blockIdx.z, tid = threadIdx.x;
-    const int dw = g->lv[level].w, dh = g->lv[level].h, dpitch = g->lv[level].pitch;
-    const int sw = g->lv[level - 1].w, sh = g->lv[level - 1].h, spitch = g->lv[level - 1].pitch;
+    const int dw = a.dw, dh = a.dh, dpitch = a.dpitch, sw = a.sw, sh = a.sh, spitch = a.spitch, ldw = a.ldw;
     const int xa = -4 + 256 * (int)blockIdx.x, ya = -3 + PR_ROWS * (int)blockIdx.y;
+    // the thread's own coefficients do not depend on the tile: they travel with the tile's range lookups
+    const int x4 = xa + 4 * (tid & 63);
+    const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + (x4 < dw + 3 ? x4 : -4) + 4);
+    uint32_t tyk[PR_ROWS / 4];
+#pragma unroll
+    for (int i = 0; i < PR_ROWS / 4; i++) tyk[i] = ytab[min(ya + (tid >> 6) + 4 * i, dh + 2) + 3];
     int lo, hi;
     vo_reflect_range(xa, min(xa + 255, dw + 2), dw, lo, hi);
     const int sx0 = (int)(xtab[lo + 4] >> 16) & ~3, sx1 = min((int)(xtab[hi + 4] >> 16) + 1, sw - 1);
     vo_reflect_range(ya, min(ya + PR_ROWS - 1, dh + 2), dh, lo, hi);
     const int sy0 = (int)(ytab[lo + 3] >> 16), sy1 = min((int)(ytab[hi + 3] >> 16) + 1, sh - 1);
     const int ndw = (sx1 - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= ldw, <= the rows the launch sized LDS for
-    const uint8_t* s = level_px((const uint8_t*)pyr, g, f, level - 1);
-    for (int i = tid; i < nrows * ndw; i += 256) {
-        const int r = i / ndw, c = i - r * ndw;
-        rs_tile[r * ldw + c] = *reinterpret_cast<const uint32_t*>(s + (ptrdiff_t)(sy0 + r) * spitch + sx0 + 4 * c);
+    const uint8_t* s = pyr + (size_t)f * a.pyr_bytes + a.soff;
+    const int items = nrows * ndw;
+    for (int i0 = 0; i0 < items; i0 += 1024) {  // four loads in flight per thread
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 256 * u + tid, items - 1);
+            const int r = i / ndw, c = i - r * ndw;
+            d[u] = *reinterpret_cast<const uint32_t*>(s + (ptrdiff_t)(sy0 + r) * spitch + sx0 + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) pin_loaded(d[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + 256 * u + tid;
+            const int r = i / ndw, c = i - r * ndw;
+            if (i < items) rs_tile[r * ldw + c] = d[u];
+        }
     }
     __syncthreads();
-    const int x4 = xa + 4 * (tid & 63);
     if (x4 >= dw + 3) return;
-    const uint4 tx4 = *reinterpret_cast<const uint4*>(xtab + x4 + 4);
     const uint32_t tx[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
     const uint8_t* t8 = reinterpret_cast<const uint8_t*>(rs_tile) - sx0;
-    uint8_t* dst = level_px(pyr, g, f, level);
-    for (int k = tid >> 6; k < PR_ROWS; k += 4) {
-        const int y = ya + k;
+    uint8_t* dst = pyr + (size_t)f * a.pyr_bytes + a.doff;
+#pragma unroll
+    for (int i = 0; i < PR_ROWS / 4; i++) {
+        const int y = ya + (tid >> 6) + 4 * i;
         if (y >= dh + 3) break;
-        const uint32_t ty = ytab[y + 3];
+        const uint32_t ty = tyk[i];
         const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
         const int oy1 = min(oy + 1, sh - 1);
         const uint8_t* r0 = t8 + (oy - sy0) * ldw * 4;
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
                                                    const unsigned long long* __restrict__ masks,
                                                    int* __restrict__ segbase, int* __restrict__ lvlofs) {
     __shared__ int wtot[16];
-    __shared__ int lvl[VO_ORB_MAX_LEVELS + 1];
+    __shared__ int s_total;
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = g->segs_total, nlevels = g->nlevels;
     const int per = ((total + 15) / 16 + 511) & ~511;  // words per wave, whole steps of 512
@@ -380,9 +408,6 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
     // one wave scan per step.  Up to RS_STEPS steps per wave (the usual geometry needs three) are read
     // once, every load in flight together, and their popcounts stay in registers for the second pass;
     // the table is padded (VO_MASK_PAD words) so these loads need no bounds.
-    int seg0[VO_ORB_MAX_LEVELS];  // level starts, in registers for the loops below
-#pragma unroll
-    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) seg0[l] = l < nlevels ? g->lv[l].seg0 : -1;
     constexpr int RS_STEPS = 4;
     static_assert((RS_STEPS + 15) * 512 <= VO_MASK_PAD, "the last wave starts at most 15 * 512 words past the table end");
     if (per <= RS_STEPS * 512) {
@@ -426,17 +451,12 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = ib + u;
-                if (i < end) {
-                    SB[i] = base;
-#pragma unroll
-                    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
-                        if (i == seg0[l]) lvl[l] = base;
-                }
+                if (i < end) SB[i] = base;
                 base += c[s][u];
             }
             run += __shfl(inc, 63);
         }
-        if (wv == 15 && lane == 0) lvl[nlevels] = run;
+        if (wv == 15 && lane == 0) s_total = run;
     } else {
         int sum = 0;
         for (int i0 = beg; i0 < end; i0 += 512) {
@@ -470,20 +490,19 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = ib + u;
-                if (i < end) {
-                    SB[i] = base;
-#pragma unroll
-                    for (int l = 0; l < VO_ORB_MAX_LEVELS; l++)
-                        if (i == seg0[l]) lvl[l] = base;
-                }
+                if (i < end) SB[i] = base;
                 base += c[u];
             }
             run += __shfl(inc, 63);
         }
-        if (wv == 15 && lane == 0) lvl[nlevels] = run;
+        if (wv == 15 && lane == 0) s_total = run;
     }
+    // the level starts are entries of the table just written (made visible to the block by the barrier)
     __syncthreads();
-    if ((int)threadIdx.x <= nlevels) lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] = lvl[threadIdx.x];
+    if ((int)threadIdx.x < nlevels)
+        lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] = SB[g->lv[threadIdx.x].seg0];
+    else if ((int)threadIdx.x == nlevels)
+        lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + nlevels] = s_total;
 }
 
 // One thread per 64-pixel segment: its keypoints go to the candidate list in x order.
@@ -1143,9 +1162,17 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
                        const uint32_t* xtab, const uint32_t* ytab, int ldw, int lrows, int nframes) {
-    dim3 grid(cdiv(hg.lv[level].w + 7, 256), cdiv(hg.lv[level].h + 6, PR_ROWS), nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * lrows * 4, st, d_geom, pyr, level, xtab, ytab,
-                       ldw);
+    (void)d_geom;
+    const LevelGeom &D = hg.lv[level], &S = hg.lv[level - 1];
+    ResizeArgs a;
+    a.dw = D.w, a.dh = D.h, a.dpitch = D.pitch;
+    a.sw = S.w, a.sh = S.h, a.spitch = S.pitch;
+    a.soff = S.offset + (unsigned)(VO_PADY * S.pitch + VO_PADX);
+    a.doff = D.offset + (unsigned)(VO_PADY * D.pitch + VO_PADX);
+    a.pyr_bytes = hg.pyr_bytes;
+    a.ldw = ldw;
+    dim3 grid(cdiv(D.w + 7, 256), cdiv(D.h + 6, PR_ROWS), nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * lrows * 4, st, pyr, a, xtab, ytab);
 }
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
