@@ -17,6 +17,11 @@ __device__ __forceinline__ uint8_t* level_px(uint8_t* buf, const PyrGeom* g, int
     return buf + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)VO_PADY * g->lv[l].pitch + VO_PADX;
 }
 
+// number of set bits of a wave mask below the calling lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int mbcnt(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // Pins a loaded value at this point of the program: without it the compiler sinks a load whose only
 // use is conditional into the branch, which turns a batch of independent loads into a chain of
 // load -> wait -> load.
@@ -95,22 +100,24 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
     const int sy0 = (int)(ytab[lo + 3] >> 16), sy1 = min((int)(ytab[hi + 3] >> 16) + 1, sh - 1);
     const int ndw = (sx1 - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= ldw, <= the rows the launch sized LDS for
     const uint8_t* s = pyr + (size_t)f * a.pyr_bytes + a.soff;
-    const int items = nrows * ndw;
-    for (int i0 = 0; i0 < items; i0 += 1024) {  // four loads in flight per thread
-        uint32_t d[4];
+    // tile fill without divisions: half a block per source row (columns c, c + 128, ...), six rows
+    // of loads in flight per thread
+    const int c0 = tid & 127, rh = tid >> 7;
+    for (int cb = 0; cb < ndw; cb += 128) {
+        const int c = cb + c0;
+        const uint8_t* col = s + (ptrdiff_t)sy0 * spitch + sx0 + 4 * min(c, ndw - 1);
+        for (int r0 = 0; r0 < nrows; r0 += 12) {
+            uint32_t d[6];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = min(i0 + 256 * u + tid, items - 1);
-            const int r = i / ndw, c = i - r * ndw;
-            d[u] = *reinterpret_cast<const uint32_t*>(s + (ptrdiff_t)(sy0 + r) * spitch + sx0 + 4 * c);
-        }
+            for (int u = 0; u < 6; u++)
+                d[u] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)min(r0 + rh + 2 * u, nrows - 1) * spitch);
 #pragma unroll
-        for (int u = 0; u < 4; u++) pin_loaded(d[u]);
+            for (int u = 0; u < 6; u++) pin_loaded(d[u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + 256 * u + tid;
-            const int r = i / ndw, c = i - r * ndw;
-            if (i < items) rs_tile[r * ldw + c] = d[u];
+            for (int u = 0; u < 6; u++) {
+                const int r = r0 + rh + 2 * u;
+                if (c < ndw && r < nrows) rs_tile[r * ldw + c] = d[u];
+            }
         }
     }
     __syncthreads();
@@ -125,16 +132,16 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
         const uint32_t ty = tyk[i];
         const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
         const int oy1 = min(oy + 1, sh - 1);
-        const uint8_t* r0 = t8 + (oy - sy0) * ldw * 4;
-        const uint8_t* r1 = t8 + (oy1 - sy0) * ldw * 4;
+        const uint8_t* r0 = t8 + __umul24(oy - sy0, ldw * 4);  // 24-bit multiplies: full rate, exact here
+        const uint8_t* r1 = t8 + __umul24(oy1 - sy0, ldw * 4);
         uint32_t out = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int ox = tx[j] >> 16, cx1 = tx[j] & 0xffff, cx0 = 256 - cx1;
             const int ox1 = min(ox + 1, sw - 1);
-            const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-            const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
-            const uint32_t v = (cy0 * h0 + cy1 * h1 + 32768u) >> 16;
+            const uint32_t h0 = __umul24(cx0, r0[ox]) + __umul24(cx1, r0[ox1]);  // <= 256 * 255
+            const uint32_t h1 = __umul24(cx0, r1[ox]) + __umul24(cx1, r1[ox1]);
+            const uint32_t v = (__umul24(cy0, h0) + __umul24(cy1, h1) + 32768u) >> 16;
             out |= min(v, 255u) << (8 * j);
         }
         *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
@@ -204,38 +211,46 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
             if (tid + 256 * s < N0) px4[tid + 256 * s] = d[s];
     }
     static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
-    for (int i = tid; i < SM_H * (SM_W + 2) / 4; i += 256) reinterpret_cast<uint32_t*>(&sm[0][0])[i] = 0;
+    {
+        constexpr int SM_DW = SM_H * (SM_W + 2) / 4;
+        static_assert(SM_DW > 512 && SM_DW <= 768, "three stores per thread clear the score map");
+        uint32_t* sm32 = reinterpret_cast<uint32_t*>(&sm[0][0]);
+        sm32[tid] = 0;
+        sm32[tid + 256] = 0;
+        if (tid < SM_DW - 512) sm32[tid + 512] = 0;
+    }
     if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
     __syncthreads();
 
-    const int wv = tid >> 6, lane = tid & 63;
-    const unsigned long long lt = lanemask_lt();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
 
     // phase A: compass test.  Wave w takes the rows w, w + 4, ... of the score region with lane =
     // column; columns 64 and 65 of all rows are one more step for waves 2 and 3 (they have a row less).
+    // Branch-free per row: the LDS reads are in range for every (sy, sx) of the score region, the
+    // image-border conditions are folded into the survivor mask, so that mask is the ballot itself.
     {
         int nloc = 0;
         uint16_t* mine = listA + wv * FT_LCAP;
         auto compass = [&](int sy, int sx, bool in) {
-            bool surv = false;
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-            if (in && x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-                const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-                const int v = c[0], lo = v - threshold, hi = v + threshold;
-                const int r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
-                const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
-                const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
-                surv = (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0) || (b0 && b4) || (b4 && b8) ||
-                       (b8 && b12) || (b12 && b0);
-            }
+            const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+            const int v = c[0], lo = v - threshold, hi = v + threshold;
+            const int r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
+            const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
+            const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
+            // two adjacent compass points of one polarity = one of {0, 8} and one of {4, 12}
+            const bool surv = in && x >= 3 && x < w - 3 && y >= 3 && y < h - 3 &&
+                              (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12)));
             const unsigned long long m = __ballot(surv);
-            if (surv) mine[nloc + __popcll(m & lt)] = (uint16_t)((sy << 7) | sx);
-            nloc += __popcll(m);
+            if (m) {
+                if (surv) mine[nloc + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
+                nloc += __popcll(m);
+            }
         };
         for (int sy = wv; sy < SM_H; sy += 4) compass(sy, lane, true);
         if (wv >= 2) {
             const int q = (wv - 2) * 64 + lane;  // 0 .. 2 * SM_H - 1
-            compass(q >> 1, FT_W + (q & 1), q < 2 * SM_H);
+            compass(min(q >> 1, SM_H - 1), FT_W + (q & 1), q < 2 * SM_H);
         }
         if (lane == 0) cntA[wv] = nloc;
     }
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 corner = ((rd | rb) & 0xffffu) != 0;
             }
             const unsigned long long m = __ballot(corner);
-            if (corner) mine[nloc + __popcll(m & lt)] = (uint16_t)p;
+            if (corner) mine[nloc + mbcnt(m)] = (uint16_t)p;
             nloc += __popcll(m);
         }
         if (lane == 0) cntB[wv] = nloc;
@@ -581,9 +596,9 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
             for (int j = 1; j <= 7; j++) {
                 const int Ix = S[j + 1] - S[j - 1];
                 const int Iy = D[j - 1] + 2 * D[j] + D[j + 1];
-                a += Ix * Ix;
-                b += Iy * Iy;
-                c += Ix * Iy;
+                a += __mul24(Ix, Ix);  // |Ix|, |Iy| <= 1020: 24-bit multiplies are exact and full rate
+                b += __mul24(Iy, Iy);
+                c += __mul24(Ix, Iy);
             }
         }
     }
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
     for (int j = 0; j < 5; j++) {
         const int item = min(lane + 64 * j, 31 * 9 - 1);
         const int row = item / 9, k = item - row * 9;
-        dw[j] = *reinterpret_cast<const uint32_t*>(base + (row - 15) * pitch + 4 * k);
+        dw[j] = *reinterpret_cast<const uint32_t*>(base + __mul24(row - 15, pitch) + 4 * k);
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -951,8 +966,8 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
             const uint32_t d = dw[j] & mask;
             const int sb = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
             const int sj = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
-            m10 += u0 * sb + sj;
-            m01 += v * sb;
+            m10 += __mul24(u0, sb) + sj;  // |u0|, |v| <= 18, sb <= 1020
+            m01 += __mul24(v, sb);
         }
     }
 #pragma unroll
