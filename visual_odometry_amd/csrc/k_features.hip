@@ -892,20 +892,55 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// Byte masks of the disc: entry [|v|][o][k] keeps the bytes of dword k of the 36-byte row window (which
+// starts o = 0..3 pixels left of u = -15) whose u lies within the row's half-width.  Compile-time table.
+struct IcMaskTab {
+    uint32_t m[16][4][12];  // nine dwords used, padded to 48 bytes for 16-byte loads
+};
+constexpr IcMaskTab make_ic_masks() {
+    IcMaskTab t{};
+    const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int a = 0; a < 16; a++)
+        for (int o = 0; o < 4; o++)
+            for (int k = 0; k < 9; k++) {
+                uint32_t m = 0;
+                for (int j = 0; j < 4; j++) {
+                    const int u = 4 * k + j - 15 - o;
+                    if (u >= -um[a] && u <= um[a]) m |= 0xffu << (8 * j);
+                }
+                t.m[a][o][k] = m;
+            }
+    return t;
+}
+__constant__ __attribute__((aligned(16))) IcMaskTab c_ic_masks = make_ic_masks();
+
+// sum over the 16 lanes of a DPP row, left in every lane of the row
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);  // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);  // row_ror:1
+    return v;
+}
+
+// Two keypoints per wave: lane r of a half-wave owns row v = r - 15 of the 31 x 31 patch, reads its
+// 36-byte window (nine aligned dwords) and its nine mask dwords, and takes sum(b) and sum((4k + j) b)
+// with two accumulating v_dot4_u32_u8 per dword: m10 = sum((4k + j) b) - (15 + o) sum(b), m01 = v sum(b).
+// Integer sums: the same m10, m01 as a per-pixel loop.  Few dependent loads: the per-level counts and
+// offsets of the frame arrive together (uniform addresses), the level's geometry is fetched while the
+// selidx -> cand chain is in flight, the row and mask loads go out together.
 __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   const Cand* __restrict__ sel, const Cand* __restrict__ cand,
                                                   int max_cand, const int* __restrict__ selidx,
                                                   const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
-    // half-width of the disc per |row|: {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}, one nibble each
-    const unsigned long long umax_nibbles = 0x3689abcddeeeffffull;
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (k >= nkp[f]) return;
-    // Few dependent loads: the per-level counts and offsets of the frame arrive together (uniform
-    // addresses), the level's geometry is fetched while the selidx -> cand chain is in flight.
+    const int n = nkp[f];
+    if ((int)(blockIdx.x * 8 + 2 * (threadIdx.x >> 6)) >= n) return;  // the whole wave
+    const int k = min((int)(blockIdx.x * 8 + (threadIdx.x >> 5)), n - 1);
+    const bool live = (int)(blockIdx.x * 8 + (threadIdx.x >> 5)) < n;
+    const int r = min((int)threadIdx.x & 31, 30);
     Cand cd;
     int lg;
     if (sel) {
@@ -921,7 +956,7 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
             ofs[i] = lo[i];
         }
         const int nl = g->nlevels;
-        int l = nl, rem = k, base = 0;
+        int l = 0, rem = k, base = 0;
         bool found = false;
 #pragma unroll
         for (int i = 0; i < VO_ORB_MAX_LEVELS; i++)
@@ -934,54 +969,51 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
                     rem -= cnt[i];
                 }
             }
-        if (!found) return;  // k < nkp = sum of the counts: not reached
-        lg = __builtin_amdgcn_readfirstlane(l);
+        if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
+        lg = l;
         const int idx = selidx[(size_t)f * max_cand + base + rem];
         cd = cand[(size_t)f * max_cand + idx];
     }
     const int pitch = g->lv[lg].pitch;
-    const float lscale = g->lv[lg].scale;
-    // The 31 x 31 patch is read as 31 rows x 9 aligned dwords (279 work items over the wave); a work
-    // item masks the bytes outside the disc and takes sum(b) and sum(j b) with two v_dot4_u32_u8:
-    // sum(u b) = u(first byte) sum(b) + sum(j b).  Integer sums: the same m10, m01 as a per-pixel loop.
+    const unsigned lofs = g->lv[lg].offset;
+    float lscale = g->lv[lg].scale;
+    pin_loaded(lscale);  // with the other loads, not at the end of the wave's life
+    pin_loaded(cd.harris);
     const int xw = (cd.x - 15) & ~3, o = (cd.x - 15) - xw;
-    const uint8_t* base = level_px(pyr, g, f, lg) + (ptrdiff_t)cd.y * pitch + xw;
-    int m01 = 0, m10 = 0;
-    uint32_t dw[5];  // all five loads are issued before the first is used
+    const int v = r - 15;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(pyr + (size_t)f * g->pyr_bytes + lofs +
+                                                            (size_t)__mul24(VO_PADY + cd.y + v, pitch) + VO_PADX + xw);
+    const uint32_t* msk = c_ic_masks.m[v < 0 ? -v : v][o];
+    uint32_t dw[9], mk[9];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int item = min(lane + 64 * j, 31 * 9 - 1);
-        const int row = item / 9, k = item - row * 9;
-        dw[j] = *reinterpret_cast<const uint32_t*>(base + __mul24(row - 15, pitch) + 4 * k);
+    for (int i = 0; i < 9; i++) {
+        dw[i] = row[i];
+        mk[i] = msk[i];
     }
+    uint32_t sb = 0, sw = 0;
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int item = min(lane + 64 * j, 31 * 9 - 1);
-        const int row = item / 9, k = item - row * 9;
-        const int v = row - 15, um = (int)(umax_nibbles >> (4 * (v < 0 ? -v : v))) & 15;
-        const int u0 = 4 * k - 15 - o;             // u of byte 0 of this dword
-        const int jlo = max(-um - u0, 0), jhi = min(um - u0, 3);
-        if (jlo <= jhi && lane + 64 * j < 31 * 9) {
-            const uint32_t mask = (0xffffffffu << (8 * jlo)) & (0xffffffffu >> (8 * (3 - jhi)));
-            const uint32_t d = dw[j] & mask;
-            const int sb = (int)__builtin_amdgcn_udot4(d, 0x01010101u, 0u, false);
-            const int sj = (int)__builtin_amdgcn_udot4(d, 0x03020100u, 0u, false);
-            m10 += __mul24(u0, sb) + sj;  // |u0|, |v| <= 18, sb <= 1020
-            m01 += __mul24(v, sb);
-        }
+    for (int i = 0; i < 9; i++) {
+        const uint32_t d = dw[i] & mk[i];
+        sb = __builtin_amdgcn_udot4(d, 0x01010101u, sb, false);
+        sw = __builtin_amdgcn_udot4(d, 0x03020100u + 0x04040404u * i, sw, false);
     }
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-        m10 += __shfl_xor(m10, o2);
-        m01 += __shfl_xor(m01, o2);
-    }
-    if (lane == 0) {
+    int m10 = (int)sw - __mul24(15 + o, (int)sb), m01 = __mul24(v, (int)sb);
+    if (!live || (threadIdx.x & 31) == 31) m10 = m01 = 0;
+    m10 = row16_sum(m10);
+    m01 = row16_sum(m01);
+    // halves of the wave: rows 0-1 and rows 2-3
+    const int a10 = __builtin_amdgcn_readlane(m10, 0) + __builtin_amdgcn_readlane(m10, 16);
+    const int b10 = __builtin_amdgcn_readlane(m10, 32) + __builtin_amdgcn_readlane(m10, 48);
+    const int a01 = __builtin_amdgcn_readlane(m01, 0) + __builtin_amdgcn_readlane(m01, 16);
+    const int b01 = __builtin_amdgcn_readlane(m01, 32) + __builtin_amdgcn_readlane(m01, 48);
+    if (live && (threadIdx.x & 31) == 0) {
+        const bool hi = (threadIdx.x & 32) != 0;
         const float s = lscale;
         vo_keypoint kp;
         kp.x = (float)cd.x * s;
         kp.y = (float)cd.y * s;
         kp.size = 31 * s;
-        kp.angle = fast_atan2_deg((float)m01, (float)m10);
+        kp.angle = fast_atan2_deg((float)(hi ? b01 : a01), (float)(hi ? b10 : a10));
         kp.response = cd.harris;
         kp.octave = cd.level;
         kp.class_id = -1;
@@ -1229,7 +1261,7 @@ void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, 
                      int max_cand, const int* selidx, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes) {
     if (max_n <= 0) return;
-    dim3 grid(cdiv(max_n, 4), nframes);
+    dim3 grid(cdiv(max_n, 8), nframes);
     hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, cand, max_cand, selidx, selcnt, lvlofs,
                        nkp, kp_cap, out);
 }
