@@ -22,6 +22,17 @@ def host():
     return C.CDLL(so)
 
 
+@pytest.fixture(scope="module")
+def host_fallback():
+    """The same solver with its Sturm-chain root finder compiled out (-DFP_NO_STURM): the derivative
+    bracketing finder, which the device code keeps as the fallback for degenerate chains."""
+    so = os.path.join(HERE, "cpp", "libhost_solver_nosturm.so")
+    src = os.path.join(HERE, "cpp", "host_five_point.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-DFP_NO_STURM", "-shared",
+                           "-o", so, src])
+    return C.CDLL(so)
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -46,6 +57,36 @@ def test_device_five_point_matches_oracle(host, oracle):
             assert np.abs([np.r_[q, 1] @ E @ np.r_[p, 1] for p, q in zip(a, b)]).max() < 1e-9
     diffs = np.array(diffs)
     assert np.median(diffs) < 1e-12 and np.percentile(diffs, 99) < 1e-6
+
+
+def test_sturm_and_fallback_root_finders_agree(host, host_fallback):
+    """Both finders see the same degree-10 polynomial; they must find the same real roots (count and,
+    through back-substitution, the same E up to the conditioning of the root)."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    nsol = 0
+    for trial in range(3000):
+        if trial % 3 == 0:  # a real two-view geometry with noise
+            X = rng.uniform([-8, -3, 4], [8, 3, 40], (5, 3))
+            R = synth.rotation(rng.normal(0, 0.05, 3))
+            t = rng.normal(0, 1, 3)
+            Y = X @ R.T + t / np.linalg.norm(t)
+            a = X[:, :2] / X[:, 2:] + rng.normal(0, 1e-3, (5, 2))
+            b = Y[:, :2] / Y[:, 2:] + rng.normal(0, 1e-3, (5, 2))
+        else:  # unrelated points: what most RANSAC samples with an outlier look like
+            a = rng.uniform(-0.6, 0.6, (5, 2))
+            b = rng.uniform(-0.6, 0.6, (5, 2))
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        E1, E2 = np.zeros((10, 3, 3)), np.zeros((10, 3, 3))
+        n1 = host.host_five_point(_p(a), _p(b), _p(E1))
+        n2 = host_fallback.host_five_point(_p(a), _p(b), _p(E2))
+        assert n1 == n2, f"trial {trial}: {n1} vs {n2} real roots"
+        nsol += n1
+        for E in E1[:n1]:
+            worst = max(worst, min(np.abs(E - F).max() for F in E2[:n2]))
+    assert nsol > 3000
+    assert worst < 1e-3  # ill-conditioned (nearly double) roots move by ~1e-5; typical agreement is 1e-13
 
 
 def test_device_decompose_and_triangulate_match_oracle(host, oracle):
