@@ -12,12 +12,6 @@
 
 #define KNN_TILE 256  // train descriptors per LDS tile
 
-__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // W32: uint32 words per descriptor (8 or 16); Q: queries per lane.  A block of 256 threads owns
 // 256 * Q queries (query i of a lane is q0 + i * 256 + thread) and scans rows [tbeg, tend) of the
 // train set.  The tile for the next step is fetched into registers while the current one is
@@ -80,7 +74,8 @@ __global__ __launch_bounds__(256) void k_knn2_partial(KnnArgs a) {
         const bool more = base + KNN_TILE < tend;
         if (more) fetch(base + KNN_TILE);
         const uint4* tl = tile[buf];
-        auto row = [&](int j) {
+#pragma unroll 2
+        for (int j = 0; j < n; j++) {
             uint32_t tr[W32];
 #pragma unroll
             for (int k = 0; k < V; k++) {
@@ -97,17 +92,11 @@ __global__ __launch_bounds__(256) void k_knn2_partial(KnnArgs a) {
 #pragma unroll
                 for (int k = 0; k < W32; k++) d += __builtin_popcount(qv[i][k] ^ tr[k]);
                 const uint32_t key = (d << VO_KEY_SHIFT) | idx;
-                // k1 <= k2 always, so the new second best min(k2, max(key, k1)) is the median of the three
-                k2[i] = med3_u32(key, k1[i], k2[i]);
+                const uint32_t hi = max(key, k1[i]);
                 k1[i] = min(key, k1[i]);
+                k2[i] = min(k2[i], hi);
             }
-        };
-        int j = 0;
-        for (; j + 1 < n; j += 2) {  // two rows per trip: the second row's LDS reads overlap the first row's ALU
-            row(j);
-            row(j + 1);
         }
-        if (j < n) row(j);
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
