@@ -82,7 +82,7 @@ struct vo_ctx {
 
     PyrGeom geom;  // host copy of d_geom
     int quota[VO_ORB_MAX_LEVELS];
-    int geom_w = 0, geom_h = 0, geom_levels = 0, geom_nfeatures = -1;
+    int geom_w = 0, geom_h = 0, geom_levels = 0, geom_nfeatures = -1, geom_border = -1;
     float geom_scale = 0;
     std::vector<uint32_t> coef_host;
     std::vector<size_t> coef_x, coef_y;  // per level offsets into d_coef (uint32 units)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const LevelGeom L = g->lv[l];
     const int local = blockIdx.x - L.tile0;
     const int tix = local % L.tiles_x, tiy = local / L.tiles_x;
-    const int tx0 = tix * FT_W, ty0 = tiy * FT_H;
+    const int tx0 = L.rx0 + tix * FT_W, ty0 = L.ry0 + tiy * FT_H;
     const int w = L.w, h = L.h, pitch = L.pitch;
     const uint8_t* img = level_px(pyr, g, f, l);
 
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 
     // phase E
     if (tid < FT_H) {
-        const int y = ty0 + tid;
-        if (y < h)
-            masks[(size_t)f * g->segs_total + L.seg0 + (size_t)y * L.segs + tix] =
+        const int yr = tiy * FT_H + tid;  // row inside the detector region
+        if (yr < L.rh)
+            masks[(size_t)f * g->segs_total + L.seg0 + (size_t)yr * L.segs + tix] =
                 (unsigned long long)rowmask[tid][0] | ((unsigned long long)rowmask[tid][1] << 32);
     }
 }
@@ -515,7 +515,8 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
     // the level starts are entries of the table just written (made visible to the block by the barrier)
     __syncthreads();
     if ((int)threadIdx.x < nlevels)
-        lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] = SB[g->lv[threadIdx.x].seg0];
+        lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + threadIdx.x] =
+            g->lv[threadIdx.x].seg0 < total ? SB[g->lv[threadIdx.x].seg0] : s_total;  // trailing empty levels
     else if ((int)threadIdx.x == nlevels)
         lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + nlevels] = s_total;
 }
@@ -536,12 +537,13 @@ __global__ __launch_bounds__(256) void k_cand_write(const PyrGeom* __restrict__ 
     for (int k = 1; k < g->nlevels; k++)
         if (sg >= g->lv[k].seg0) l = k;
     const int local = sg - g->lv[l].seg0;
-    const int y = local / g->lv[l].segs, sx = local - y * g->lv[l].segs;
+    const int yr = local / g->lv[l].segs, sx = local - yr * g->lv[l].segs;
+    const int y = g->lv[l].ry0 + yr, xs = g->lv[l].rx0 + sx * 64;
     const uint8_t* sc = level_px(score, g, f, l) + (size_t)y * g->lv[l].pitch;
     while (m) {
         const int bit = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const int x = sx * 64 + bit;
+        const int x = xs + bit;
         if (pos < max_cand) {
             Cand cd;
             cd.x = (int16_t)x;
@@ -1224,6 +1226,7 @@ void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
                      unsigned long long* masks, int threshold, int border, int nms, int nframes) {
+    if (hg.tiles_total == 0) return;
     dim3 grid(hg.tiles_total, nframes);
     hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms);
 }
@@ -1235,6 +1238,7 @@ void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long 
 
 void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
                        const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes) {
+    if (hg.segs_total == 0) return;
     dim3 grid(cdiv(hg.segs_total, 256), nframes);
     hipLaunchKernelGGL(k_cand_write, grid, dim3(256), 0, st, d_geom, masks, segbase, score, nms, cand, max_cand);
 }

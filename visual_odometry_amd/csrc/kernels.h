@@ -25,6 +25,10 @@ struct LevelGeom {
     int row0;         // first row of this level in the frame-wide row table
     unsigned offset;  // byte offset of the padded level inside a frame's packed buffer
     float scale;      // cv layerScale
+    // Detector region: the rectangle whose pixels can become keypoints under the border filter, plus the
+    // one-pixel ring non-maximum suppression reads (rx0 is a multiple of 4).  Tiles, mask segments and
+    // mask rows are counted inside it: segment (y, s) covers x = rx0 + 64 s .. + 63 of row ry0 + y.
+    int rx0, ry0, rw, rh;
     int seg0, segs;   // first 64-pixel row segment of this level in the frame-wide mask table, segments per row
     int tile0, tiles_x;  // first 64x32 detector tile of this level, tiles per tile row
 };

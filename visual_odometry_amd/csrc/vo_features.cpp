@@ -102,7 +102,9 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
                        c->lim.max_width, c->lim.max_height);
     if (nframes > c->lim.max_batch)
         return c->fail(VO_ERR_CAPACITY, "%d frames exceed max_batch %d", nframes, c->lim.max_batch);
-    const bool same = c->geom_w == w && c->geom_h == h && c->geom_levels == nlevels && c->geom_scale == sf;
+    const int border = p ? p->edge_threshold : 0;  // the detector skips what the border filter would drop
+    const bool same = c->geom_w == w && c->geom_h == h && c->geom_levels == nlevels && c->geom_scale == sf &&
+                      c->geom_border == border;
     if (!same) {
         PyrGeom g;
         memset(&g, 0, sizeof(g));
@@ -123,12 +125,21 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
             off += (unsigned)L.pitch * (L.h + 2 * VO_PADY);
             off = (off + 255u) & ~255u;
             row += L.h;
-            L.segs = cdiv(L.w, 64);
+            // keypoints live in [b, w - b) x [b, h - b), b = max(border, 3) (FAST itself needs 3); a level
+            // not larger than twice the border keeps none (cv's runByImageBorder)
+            const int b = std::max(border, 3);
+            const bool level_ok = border == 0 || (L.w > 2 * border && L.h > 2 * border);
+            L.rx0 = (b - 1) & ~3;
+            L.ry0 = b - 1;
+            L.rw = level_ok ? std::max(std::min(L.w, L.w - b + 1) - L.rx0, 0) : 0;
+            L.rh = level_ok ? std::max(std::min(L.h, L.h - b + 1) - L.ry0, 0) : 0;
+            if (L.rw == 0 || L.rh == 0) L.rw = L.rh = 0;
+            L.segs = cdiv(L.rw, 64);
             L.seg0 = seg;
-            seg += L.segs * L.h;
+            seg += L.segs * L.rh;
             L.tiles_x = L.segs;
             L.tile0 = tile;
-            tile += L.tiles_x * cdiv(L.h, 32);
+            tile += L.tiles_x * cdiv(L.rh, 32);
         }
         g.tiles_total = tile;
         g.segs_total = seg;
@@ -189,6 +200,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
         c->geom_h = h;
         c->geom_levels = nlevels;
         c->geom_scale = sf;
+        c->geom_border = border;
         c->geom_nfeatures = -1;
     }
     if (c->geom_nfeatures != nfeatures) {
@@ -237,6 +249,8 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
     hipStream_t st = c->stream;
     uint8_t* pyr = c->d_pyr.as<uint8_t>();
+    if (border != c->geom_border)
+        return c->fail(VO_ERR_INVALID, "feat_detect: border %d, geometry was laid out for %d", border, c->geom_border);
     launch_pyr_level0(st, d_img, frame_stride, stride, dg, g, pyr, nframes);
     for (int l = 1; l < g.nlevels; l++)
         launch_pyr_resize(st, dg, g, pyr, l, c->d_coef.as<uint32_t>() + c->coef_x[l],
