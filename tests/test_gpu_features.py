@@ -92,6 +92,23 @@ def test_orb_small_image_few_levels(vo, oracle):
     assert np.array_equal(kg, ko) and np.array_equal(dg, do)
 
 
+@pytest.mark.parametrize("h,w,edge", [(376, 1241, 19), (376, 1241, 45), (376, 1241, 64), (150, 500, 31), (70, 300, 31)])
+def test_orb_edge_thresholds_and_empty_levels(vo, oracle, frames, h, w, edge):
+    # the detector only visits the region the border filter keeps: other borders move that region, and
+    # levels not larger than twice the border (the top ones here) have no region at all
+    from visual_odometry_amd import api
+
+    img = np.ascontiguousarray(frames[0][1][:h, :w])
+    kg, dg = vo.orb_detect_compute(img, api.orb_params(1000, edge_threshold=edge))
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(1000, edge_threshold=edge))
+    assert len(ko) > (20 if h > 100 else 1)
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    # and back to the default border on the same context (the geometry is rebuilt)
+    kg, dg = vo.orb_detect_compute(img, api.orb_params(1000))
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(1000))
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+
+
 def test_orb_flat_image_gives_nothing(vo, oracle):
     from visual_odometry_amd import api
 
