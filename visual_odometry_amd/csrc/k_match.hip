@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_knn2_partial(KnnArgs a) {
         const bool more = base + KNN_TILE < tend;
         if (more) fetch(base + KNN_TILE);
         const uint4* tl = tile[buf];
-#pragma unroll 2
+#pragma unroll 4
         for (int j = 0; j < n; j++) {
             uint32_t tr[W32];
 #pragma unroll
