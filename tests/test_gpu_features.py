@@ -109,6 +109,25 @@ def test_orb_edge_thresholds_and_empty_levels(vo, oracle, frames, h, w, edge):
     assert np.array_equal(kg, ko) and np.array_equal(dg, do)
 
 
+def test_orb_full_hd_frame(oracle, frames):
+    # a frame four times KITTI's area on a context with wider limits: the mask table no longer fits the
+    # row scan's register-resident path, the resize tiles and selection lists are larger
+    from visual_odometry_amd import api
+
+    img = np.ascontiguousarray(np.tile(frames[0][1], (3, 2))[:1080, :1920])
+    ctx = api.VoContext(0, max_width=1920, max_height=1080)
+    try:
+        kg, dg = ctx.orb_detect_compute(img, api.orb_params(2000, fast_threshold=60))
+        kf = ctx.fast_detect(img, 60, True, cap=200000)
+    finally:
+        ctx.close()
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(2000, fast_threshold=60))
+    assert len(ko) >= 1800
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    fo = oracle.fast_detect(img, 60, True)
+    assert len(fo) > 5000 and np.array_equal(kf, fo)
+
+
 def test_orb_flat_image_gives_nothing(vo, oracle):
     from visual_odometry_amd import api
 
