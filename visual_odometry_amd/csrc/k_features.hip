@@ -44,25 +44,37 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 
 // ---------------------------------------------------------------------------------------------
 // Level 0: copy of the caller's image into the padded layout, with the 3-pixel reflect-101 frame.
-// One thread per aligned dword of the destination.
+// One thread per aligned 16-byte chunk of the destination (x = -16, 0, 16, ...): interior chunks are one
+// unaligned 16-byte load (caller rows have any alignment) and one aligned store, chunks that touch the
+// left or right edge are assembled byte by byte through reflect-101 (the padding bytes beyond the
+// 3-pixel frame get reflected values too; nothing reads them as pixels).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
-                                                    const PyrGeom* __restrict__ g, uint8_t* __restrict__ pyr) {
+                                                    int w, int h, int pitch, unsigned pyr_bytes, unsigned loff,
+                                                    uint8_t* __restrict__ pyr) {
     const int f = blockIdx.z;
-    const int w = g->lv[0].w, h = g->lv[0].h, pitch = g->lv[0].pitch;
-    const int x4 = -4 + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = -3 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x4 >= w + 3 || y >= h + 3) return;
+    const int x16 = -16 + 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
+    const int y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    if (x16 >= w + 3 || y >= h + 3) return;
     const uint8_t* src = img + (size_t)f * frame_stride + (size_t)reflect101(y, h) * stride;
-    uint32_t v = 0;
-    if (x4 >= 0 && x4 + 3 < w) {
-        __builtin_memcpy(&v, src + x4, 4);  // one unaligned dword load (caller rows have any alignment)
+    uint4 v;
+    if (x16 >= 0 && x16 + 15 < w) {
+        __builtin_memcpy(&v, src + x16, 16);
     } else {
+        uint32_t d[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v |= (uint32_t)src[reflect101(x4 + j, w)] << (8 * j);
+        for (int q = 0; q < 4; q++) {
+            d[q] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = min(max(x16 + 4 * q + j, -(w - 1)), 2 * w - 2);  // keep reflect101 in one fold
+                d[q] |= (uint32_t)src[reflect101(x, w)] << (8 * j);
+            }
+        }
+        v = make_uint4(d[0], d[1], d[2], d[3]);
     }
-    uint8_t* dst = level_px(pyr, g, f, 0);
-    *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * pitch + x4) = v;
+    uint8_t* dst = pyr + (size_t)f * pyr_bytes + loff;
+    *reinterpret_cast<uint4*>(dst + (ptrdiff_t)y * pitch + x16) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1205,8 +1217,11 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
 // ---------------------------------------------------------------------------------------------
 void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, int stride, const PyrGeom* d_geom,
                        const PyrGeom& hg, uint8_t* pyr, int nframes) {
-    dim3 grid(cdiv(cdiv(hg.lv[0].w + 7, 4), 64), cdiv(hg.lv[0].h + 6, 4), nframes);
-    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, d_geom, pyr);
+    (void)d_geom;
+    const LevelGeom& L = hg.lv[0];
+    dim3 grid(cdiv(cdiv(L.w + 3 + 16, 16), 64), cdiv(L.h + 6, 4), nframes);
+    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, L.w, L.h, L.pitch,
+                       hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), pyr);
 }
 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
