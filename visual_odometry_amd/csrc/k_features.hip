@@ -17,6 +17,12 @@ __device__ __forceinline__ uint8_t* level_px(uint8_t* buf, const PyrGeom* g, int
     return buf + (size_t)f * g->pyr_bytes + g->lv[l].offset + (size_t)VO_PADY * g->lv[l].pitch + VO_PADX;
 }
 
+typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, a), __builtin_bit_cast(vo_u16x2, b), c, false);
+}
+
 // number of set bits of a wave mask below the calling lane (v_mbcnt_lo / v_mbcnt_hi)
 __device__ __forceinline__ int mbcnt(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -44,21 +50,36 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 
 // ---------------------------------------------------------------------------------------------
 // Level 0: copy of the caller's image into the padded layout, with the 3-pixel reflect-101 frame.
-// One thread per aligned 16-byte chunk of the destination (x = -16, 0, 16, ...): interior chunks are one
-// unaligned 16-byte load (caller rows have any alignment) and one aligned store, chunks that touch the
-// left or right edge are assembled byte by byte through reflect-101 (the padding bytes beyond the
-// 3-pixel frame get reflected values too; nothing reads them as pixels).
+// One thread per aligned 16-byte chunk of the destination (x = -16, 0, 16, ...).  Blocks
+// blockIdx.x < nint copy interior chunks: one unaligned 16-byte load (caller rows have any alignment)
+// and one aligned store.  The last block column assembles the chunks that touch the left or right edge
+// byte by byte through reflect-101, one thread per (row, edge chunk), so the waves of the interior never
+// run that path (the padding bytes beyond the 3-pixel frame get reflected values too; nothing reads
+// them as pixels).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
                                                     int w, int h, int pitch, unsigned pyr_bytes, unsigned loff,
-                                                    uint8_t* __restrict__ pyr) {
+                                                    int nint, uint8_t* __restrict__ pyr) {
     const int f = blockIdx.z;
-    const int x16 = -16 + 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
-    const int y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
-    if (x16 >= w + 3 || y >= h + 3) return;
+    const int first_int = 0, end_int = (w - 15 > 0 ? (w - 16) / 16 + 1 : 0) * 16;  // interior chunks: [0, end_int)
+    int x16, y;
+    bool edge = false;
+    if ((int)blockIdx.x < nint) {
+        x16 = first_int + 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
+        y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+        if (x16 >= end_int || y >= h + 3) return;
+    } else {
+        // edge chunks of four rows: x = -16, then end_int, end_int + 16, ... < w + 3
+        const int nedge = 1 + (w + 3 - end_int + 15) / 16;
+        const int e = threadIdx.x & 63;
+        y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+        if (e >= nedge || y >= h + 3) return;
+        x16 = e == 0 ? -16 : end_int + 16 * (e - 1);
+        edge = true;
+    }
     const uint8_t* src = img + (size_t)f * frame_stride + (size_t)reflect101(y, h) * stride;
     uint4 v;
-    if (x16 >= 0 && x16 + 15 < w) {
+    if (!edge) {
         __builtin_memcpy(&v, src + x16, 16);
     } else {
         uint32_t d[4];
@@ -66,10 +87,7 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
         for (int q = 0; q < 4; q++) {
             d[q] = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = min(max(x16 + 4 * q + j, -(w - 1)), 2 * w - 2);  // keep reflect101 in one fold
-                d[q] |= (uint32_t)src[reflect101(x, w)] << (8 * j);
-            }
+            for (int j = 0; j < 4; j++) d[q] |= (uint32_t)src[reflect101(x16 + 4 * q + j, w)] << (8 * j);
         }
         v = make_uint4(d[0], d[1], d[2], d[3]);
     }
@@ -134,8 +152,22 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
     }
     __syncthreads();
     if (x4 >= dw + 3) return;
+    // Packed 16-bit arithmetic: the (upper row, lower row) samples of a column share a dword, so one
+    // v_pk_mul_lo_u16 + v_pk_mad_u16 interpolates both rows horizontally (h <= 256 * 255 fits 16 bits) and
+    // one v_dot2_u32_u16 with (cy0, cy1) is the vertical pass; the same integers as the scalar form.  The
+    // right / lower neighbour is read unclamped: where cv clamps it (last column / row) its weight is 0,
+    // and the launch sizes the tile one row and 16 bytes larger so the read stays inside LDS.
     const uint32_t tx[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(rs_tile) - sx0;
+    vo_u16x2 CX0[4], CX1[4];
+    int ox[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        ox[j] = (int)(tx[j] >> 16) - sx0;
+        const unsigned short c1 = (unsigned short)(tx[j] & 0xffff), c0 = (unsigned short)(256 - c1);
+        CX0[j] = vo_u16x2{c0, c0};
+        CX1[j] = vo_u16x2{c1, c1};
+    }
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(rs_tile);
     uint8_t* dst = pyr + (size_t)f * a.pyr_bytes + a.doff;
 #pragma unroll
     for (int i = 0; i < PR_ROWS / 4; i++) {
@@ -143,17 +175,15 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
         if (y >= dh + 3) break;
         const uint32_t ty = tyk[i];
         const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
-        const int oy1 = min(oy + 1, sh - 1);
-        const uint8_t* r0 = t8 + __umul24(oy - sy0, ldw * 4);  // 24-bit multiplies: full rate, exact here
-        const uint8_t* r1 = t8 + __umul24(oy1 - sy0, ldw * 4);
+        const uint32_t CY = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
+        const uint8_t* r0 = t8 + __umul24(oy - sy0, ldw * 4);
+        const uint8_t* r1 = r0 + ldw * 4;
         uint32_t out = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int ox = tx[j] >> 16, cx1 = tx[j] & 0xffff, cx0 = 256 - cx1;
-            const int ox1 = min(ox + 1, sw - 1);
-            const uint32_t h0 = __umul24(cx0, r0[ox]) + __umul24(cx1, r0[ox1]);  // <= 256 * 255
-            const uint32_t h1 = __umul24(cx0, r1[ox]) + __umul24(cx1, r1[ox1]);
-            const uint32_t v = (__umul24(cy0, h0) + __umul24(cy1, h1) + 32768u) >> 16;
+            const vo_u16x2 A = {r0[ox[j]], r1[ox[j]]}, B = {r0[ox[j] + 1], r1[ox[j] + 1]};
+            const vo_u16x2 hp = A * CX0[j] + B * CX1[j];
+            const uint32_t v = udot2(__builtin_bit_cast(uint32_t, hp), CY, 32768u) >> 16;
             out |= min(v, 255u) << (8 * j);
         }
         *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
@@ -1046,11 +1076,6 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
 // (even row, odd row) pairs: the sums are exact integers either way, the same as cv's.
 // ---------------------------------------------------------------------------------------------
 #define GB_ROWS 16
-typedef unsigned short vo_u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(vo_u16x2, a), __builtin_bit_cast(vo_u16x2, b), c, false);
-}
 
 __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                 uint8_t* __restrict__ blur, Taps7 taps, GaussGrid gg) {
@@ -1219,9 +1244,11 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
                        const PyrGeom& hg, uint8_t* pyr, int nframes) {
     (void)d_geom;
     const LevelGeom& L = hg.lv[0];
-    dim3 grid(cdiv(cdiv(L.w + 3 + 16, 16), 64), cdiv(L.h + 6, 4), nframes);
+    const int interior = L.w - 15 > 0 ? (L.w - 16) / 16 + 1 : 0;  // whole 16-byte chunks inside [0, w)
+    const int nint = cdiv(interior, 64);
+    dim3 grid(nint + 1, cdiv(L.h + 6, 4), nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, L.w, L.h, L.pitch,
-                       hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), pyr);
+                       hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), nint, pyr);
 }
 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
@@ -1236,7 +1263,7 @@ void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
     a.pyr_bytes = hg.pyr_bytes;
     a.ldw = ldw;
     dim3 grid(cdiv(D.w + 7, 256), cdiv(D.h + 6, PR_ROWS), nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * lrows * 4, st, pyr, a, xtab, ytab);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * (lrows + 1) * 4 + 16, st, pyr, a, xtab, ytab);
 }
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
