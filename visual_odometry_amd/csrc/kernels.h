@@ -58,7 +58,7 @@ static inline __host__ __device__ void vo_reflect_range(int a, int b, int n, int
     lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
 }
-#define PR_ROWS 8  // destination rows per block of the pyramid resize
+#define PR_ROWS 16  // destination rows per block of the pyramid resize
 
 struct Taps7 {
     int t[7];
