@@ -337,6 +337,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 rd &= xd >> 8;
                 rb &= xb >> 8;
                 corner = ((rd | rb) & 0xffffu) != 0;
+                // a 9-arc of one polarity excludes one of the other (16 ring points): bit 13 = dark arc
+                p |= (rd & 0xffffu) ? 0x2000 : 0;
             }
             const unsigned long long m = __ballot(corner);
             if (corner) mine[nloc + mbcnt(m)] = (uint16_t)p;
@@ -351,54 +353,29 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         return (int)listB[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? b0 : seg == 2 ? b1 : b2)];
     };
 
-    // phase C: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1
+    // phase C: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1 with
+    // d = v - ring.  Only the polarity that has the arc can exceed the threshold (the other one would
+    // need a second 9-arc), so one min network on e = +-d is enough: the same score.
     for (int i = tid; i < nb; i += 256) {
         const int p = cornerAt(i);
-        const int sy = p >> 7, sx = p & 127;
+        const int sy = (p >> 7) & 63, sx = p & 127;
         const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-        const int v = c[0];
-        int d[16];
-        d[0] = v - c[3 * PX_W + 0];
-        d[1] = v - c[3 * PX_W + 1];
-        d[2] = v - c[2 * PX_W + 2];
-        d[3] = v - c[1 * PX_W + 3];
-        d[4] = v - c[3];
-        d[5] = v - c[-1 * PX_W + 3];
-        d[6] = v - c[-2 * PX_W + 2];
-        d[7] = v - c[-3 * PX_W + 1];
-        d[8] = v - c[-3 * PX_W + 0];
-        d[9] = v - c[-3 * PX_W - 1];
-        d[10] = v - c[-2 * PX_W - 2];
-        d[11] = v - c[-1 * PX_W - 3];
-        d[12] = v - c[-3];
-        d[13] = v - c[1 * PX_W - 3];
-        d[14] = v - c[2 * PX_W - 2];
-        d[15] = v - c[3 * PX_W - 1];
+        const int sgn = (p & 0x2000) ? 1 : -1;
+        const int sv = sgn * (int)c[0];
+        int e[16];
+#define VO_E(k, dx, dy) e[k] = sv - sgn * (int)c[(dy) * PX_W + (dx)];
+        VO_E(0, 0, 3) VO_E(1, 1, 3) VO_E(2, 2, 2) VO_E(3, 3, 1) VO_E(4, 3, 0) VO_E(5, 3, -1) VO_E(6, 2, -2)
+        VO_E(7, 1, -3) VO_E(8, 0, -3) VO_E(9, -1, -3) VO_E(10, -2, -2) VO_E(11, -3, -1) VO_E(12, -3, 0)
+        VO_E(13, -3, 1) VO_E(14, -2, 2) VO_E(15, -1, 3)
+#undef VO_E
         int best = threshold;
-        {
-            int m2[16], m4[16];
+        int m2[16], m4[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m2[k] = min(e[k], e[(k + 1) & 15]);
 #pragma unroll
-            for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+        for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int m8 = min(m4[k], m4[(k + 4) & 15]);
-                best = max(best, min(m8, d[(k + 8) & 15]));
-            }
-        }
-        {
-            int m2[16], m4[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) m2[k] = max(d[k], d[(k + 1) & 15]);
-#pragma unroll
-            for (int k = 0; k < 16; k++) m4[k] = max(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int m8 = max(m4[k], m4[(k + 4) & 15]);
-                best = max(best, -max(m8, d[(k + 8) & 15]));
-            }
-        }
+        for (int k = 0; k < 16; k++) best = max(best, min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
         sm[sy][sx] = (uint8_t)best;  // (best - 1) + 1
     }
     __syncthreads();
@@ -409,7 +386,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     uint8_t* sc = level_px(score, g, f, l);
     for (int i = tid; i < nb; i += 256) {
         const int p = cornerAt(i);
-        const int sy = p >> 7, sx = p & 127;
+        const int sy = (p >> 7) & 63, sx = p & 127;
         if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;
         const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
         if (!level_ok || x < b || x >= w - b || y < b || y >= h - b) continue;
