@@ -57,42 +57,51 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // run that path (the padding bytes beyond the 3-pixel frame get reflected values too; nothing reads
 // them as pixels).
 // ---------------------------------------------------------------------------------------------
+#define L0_ROWS 4  // rows per thread: four independent 16-byte loads in flight
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
                                                     int w, int h, int pitch, unsigned pyr_bytes, unsigned loff,
                                                     int nint, uint8_t* __restrict__ pyr) {
     const int f = blockIdx.z;
-    const int first_int = 0, end_int = (w - 15 > 0 ? (w - 16) / 16 + 1 : 0) * 16;  // interior chunks: [0, end_int)
-    int x16, y;
-    bool edge = false;
+    const int end_int = (w - 15 > 0 ? (w - 16) / 16 + 1 : 0) * 16;  // interior chunks: x = 0, 16, ... < end_int
+    const int y0 = -3 + ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * L0_ROWS;
+    if (y0 >= h + 3) return;
+    const uint8_t* fimg = img + (size_t)f * frame_stride;
+    uint8_t* dst = pyr + (size_t)f * pyr_bytes + loff;
     if ((int)blockIdx.x < nint) {
-        x16 = first_int + 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
-        y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
-        if (x16 >= end_int || y >= h + 3) return;
+        const int x16 = 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
+        if (x16 >= end_int) return;
+        uint4 v[L0_ROWS];
+#pragma unroll
+        for (int i = 0; i < L0_ROWS; i++)
+            __builtin_memcpy(&v[i], fimg + (size_t)reflect101(min(y0 + i, h + 2), h) * stride + x16, 16);
+#pragma unroll
+        for (int i = 0; i < L0_ROWS; i++) {
+            pin_loaded(v[i].x);
+            pin_loaded(v[i].y);
+            pin_loaded(v[i].z);
+            pin_loaded(v[i].w);
+        }
+#pragma unroll
+        for (int i = 0; i < L0_ROWS; i++)
+            if (y0 + i < h + 3) *reinterpret_cast<uint4*>(dst + (ptrdiff_t)(y0 + i) * pitch + x16) = v[i];
     } else {
-        // edge chunks of four rows: x = -16, then end_int, end_int + 16, ... < w + 3
+        // edge chunks: x = -16, then end_int, end_int + 16, ... < w + 3
         const int nedge = 1 + (w + 3 - end_int + 15) / 16;
         const int e = threadIdx.x & 63;
-        y = -3 + (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
-        if (e >= nedge || y >= h + 3) return;
-        x16 = e == 0 ? -16 : end_int + 16 * (e - 1);
-        edge = true;
-    }
-    const uint8_t* src = img + (size_t)f * frame_stride + (size_t)reflect101(y, h) * stride;
-    uint4 v;
-    if (!edge) {
-        __builtin_memcpy(&v, src + x16, 16);
-    } else {
-        uint32_t d[4];
+        if (e >= nedge) return;
+        const int x16 = e == 0 ? -16 : end_int + 16 * (e - 1);
+        for (int i = 0; i < L0_ROWS && y0 + i < h + 3; i++) {
+            const uint8_t* src = fimg + (size_t)reflect101(y0 + i, h) * stride;
+            uint32_t d[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            d[q] = 0;
+            for (int q = 0; q < 4; q++) {
+                d[q] = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) d[q] |= (uint32_t)src[reflect101(x16 + 4 * q + j, w)] << (8 * j);
+                for (int j = 0; j < 4; j++) d[q] |= (uint32_t)src[reflect101(x16 + 4 * q + j, w)] << (8 * j);
+            }
+            *reinterpret_cast<uint4*>(dst + (ptrdiff_t)(y0 + i) * pitch + x16) = make_uint4(d[0], d[1], d[2], d[3]);
         }
-        v = make_uint4(d[0], d[1], d[2], d[3]);
     }
-    uint8_t* dst = pyr + (size_t)f * pyr_bytes + loff;
-    *reinterpret_cast<uint4*>(dst + (ptrdiff_t)y * pitch + x16) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1223,7 +1232,7 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
     const LevelGeom& L = hg.lv[0];
     const int interior = L.w - 15 > 0 ? (L.w - 16) / 16 + 1 : 0;  // whole 16-byte chunks inside [0, w)
     const int nint = cdiv(interior, 64);
-    dim3 grid(nint + 1, cdiv(L.h + 6, 4), nframes);
+    dim3 grid(nint + 1, cdiv(L.h + 6, 4 * L0_ROWS), nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, L.w, L.h, L.pitch,
                        hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), nint, pyr);
 }
