@@ -74,6 +74,17 @@ struct vo_ctx {
     PinnedBuf h_lvlofs, h_cand, h_sel, h_nkp, h_misc, h_flags;
     PinnedBuf h_img;  // two staging slots for vo_upload_image
     int h_img_slot = 0;
+    // Pinned arena for the small transfers of an entry point (points, masks, matrices): a copy from or to
+    // the caller's pageable memory blocks the host for ~30 us each, a pinned one is queued in ~5.  Inputs
+    // are copied into the arena and sent asynchronously; outputs land in the arena and vo_xfer_finish
+    // (synchronise + copy out) hands them to the caller.  The arena is recycled at every finish.
+    PinnedBuf h_xfer;
+    size_t xfer_used = 0;
+    struct XferOut {
+        void* host;
+        size_t offset, bytes;
+    };
+    std::vector<XferOut> xfer_out;
     int max_cand = 65536;
     int last_flags = 0;  // OR of the VO_SEL_* flags of the last batch
     int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
@@ -158,6 +169,10 @@ int vo_ensure(vo_ctx* ctx, DevBuf& b, size_t bytes);
 int vo_ensure_pinned(vo_ctx* ctx, PinnedBuf& b, size_t bytes);
 int vo_check_launch(vo_ctx* ctx, const char* what);
 int vo_upload_image(vo_ctx* c, DevBuf& dst, const uint8_t* gray, int w, int h, int stride);
+int vo_xfer_begin(vo_ctx* c);                                            // first thing in an entry point
+int vo_xfer_in(vo_ctx* c, void* dev, const void* host, size_t bytes);    // host -> device on c->stream
+int vo_xfer_out(vo_ctx* c, void* host, const void* dev, size_t bytes);   // device -> host, valid after finish
+int vo_xfer_finish(vo_ctx* c);                                           // synchronise, deliver the outputs
 
 // features (vo_features.cpp)
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);

@@ -45,6 +45,68 @@ int vo_upload_image(vo_ctx* c, DevBuf& dst, const uint8_t* gray, int w, int h, i
     return VO_OK;
 }
 
+// ---- pinned transfer arena (see ctx.h) ----------------------------------------------------------
+static const size_t kXferAlign = 64;
+
+static uint8_t* xfer_slot(vo_ctx* c, size_t bytes, size_t* offset) {
+    if (!c->h_xfer.p) {
+        // sized once (growing would move slots that copies in flight still use): every per-point array
+        // of an entry point, twice over
+        const size_t want = std::max<size_t>(1 << 20, (size_t)c->lim.max_points * 256);
+        if (vo_ensure_pinned(c, c->h_xfer, want) != VO_OK) return nullptr;
+        c->xfer_used = 0;
+    }
+    const size_t at = (c->xfer_used + kXferAlign - 1) & ~(kXferAlign - 1);
+    if (at + bytes > c->h_xfer.cap) return nullptr;  // the caller falls back to a direct copy
+    c->xfer_used = at + bytes;
+    if (offset) *offset = at;
+    return c->h_xfer.as<uint8_t>() + at;
+}
+
+// Start of an entry point: an earlier call that failed between its transfers and its finish may have
+// left copies in flight and outputs registered; let them drain and drop them.
+int vo_xfer_begin(vo_ctx* c) {
+    if (c->xfer_used != 0 || !c->xfer_out.empty()) {
+        (void)hipStreamSynchronize(c->stream);
+        c->xfer_out.clear();
+        c->xfer_used = 0;
+    }
+    return VO_OK;
+}
+
+int vo_xfer_in(vo_ctx* c, void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return VO_OK;
+    uint8_t* slot = xfer_slot(c, bytes, nullptr);
+    if (slot) {
+        memcpy(slot, host, bytes);
+        host = slot;
+    }
+    VO_HIP(c, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+
+int vo_xfer_out(vo_ctx* c, void* host, const void* dev, size_t bytes) {
+    if (bytes == 0) return VO_OK;
+    size_t off = 0;
+    uint8_t* slot = xfer_slot(c, bytes, &off);
+    if (slot) {
+        c->xfer_out.push_back({host, off, bytes});
+        host = slot;
+    }
+    VO_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return VO_OK;
+}
+
+int vo_xfer_finish(vo_ctx* c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        for (const auto& o : c->xfer_out) memcpy(o.host, c->h_xfer.as<uint8_t>() + o.offset, o.bytes);
+    c->xfer_out.clear();
+    c->xfer_used = 0;
+    if (e != hipSuccess) return c->fail(VO_ERR_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    return VO_OK;
+}
+
 int vo_check_launch(vo_ctx* ctx, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ctx->fail(VO_ERR_DEVICE, "%s: launch failed: %s", what, hipGetErrorString(e));
@@ -129,7 +191,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
-                        &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img};
+                        &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img,
+                        &c->h_xfer};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < VO_PROF_COUNT; i++) {

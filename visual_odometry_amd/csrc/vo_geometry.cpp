@@ -205,8 +205,8 @@ static int upload_points(vo_ctx* c, const float* p0, const float* p1, int n) {
     VO_TRY(vo_ensure(c, c->d_fp0, (size_t)std::max(n, 1) * sizeof(float2)));
     VO_TRY(vo_ensure(c, c->d_fp1, (size_t)std::max(n, 1) * sizeof(float2)));
     if (n > 0) {
-        VO_HIP(c, hipMemcpyAsync(c->d_fp0.p, p0, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        VO_HIP(c, hipMemcpyAsync(c->d_fp1.p, p1, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        VO_TRY(vo_xfer_in(c, c->d_fp0.p, p0, (size_t)n * sizeof(float2)));
+        VO_TRY(vo_xfer_in(c, c->d_fp1.p, p1, (size_t)n * sizeof(float2)));
     }
     return VO_OK;
 }
@@ -223,14 +223,15 @@ int vo_find_essential(vo_ctx* c, const float* p0, const float* p1, int n, const 
     for (int i = 0; i < 9; i++) E[i] = 0;
     if (mask && n > 0) memset(mask, 0, n);
     if (n < 5) return c->fail(VO_ERR_FAILED, "vo_find_essential: %d points, 5 needed", n);
+    VO_TRY(vo_xfer_begin(c));
     VO_TRY(geom_prepare(c, 1, n, seed, max_iters));
     VO_TRY(upload_points(c, p0, p1, n));
     VO_TRY(geom_find_essential_dev(c, 1, n, c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), nullptr, n, K, method,
                                    prob, threshold, max_iters));
     VO_TRY(vo_ensure_pinned(c, c->h_state, sizeof(EstState)));
     VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, sizeof(EstState), hipMemcpyDeviceToHost, c->stream));
-    if (mask) VO_HIP(c, hipMemcpyAsync(mask, c->d_mask.p, n, hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+    if (mask) VO_TRY(vo_xfer_out(c, mask, c->d_mask.p, n));
+    VO_TRY(vo_xfer_finish(c));
     const EstState* s = c->h_state.as<EstState>();
     if (s->status != VO_OK) {
         if (mask) memset(mask, 0, n);
@@ -254,21 +255,20 @@ int vo_recover_pose(vo_ctx* c, const double* E, const float* p0, const float* p1
     VO_TRY(vo_ensure(c, c->d_mask, (size_t)n_cap));
     VO_TRY(vo_ensure(c, c->d_cam, sizeof(CamK)));
     VO_TRY(vo_ensure(c, c->d_proj, 24 * sizeof(double)));
+    VO_TRY(vo_xfer_begin(c));
     VO_TRY(upload_points(c, p0, p1, n));
-    VO_HIP(c, hipMemcpyAsync(c->d_proj.p, E, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (mask_inout && n > 0)
-        VO_HIP(c, hipMemcpyAsync(c->d_mask.p, mask_inout, n, hipMemcpyHostToDevice, c->stream));
+    VO_TRY(vo_xfer_in(c, c->d_proj.p, E, 9 * sizeof(double)));
+    if (mask_inout && n > 0) VO_TRY(vo_xfer_in(c, c->d_mask.p, mask_inout, n));
     VO_TRY(geom_recover_pose_dev(c, 1, n_cap, c->d_proj.as<double>(), 0, c->d_fp0.as<float2>(),
                                  c->d_fp1.as<float2>(), nullptr, n, K, dist_thresh, mask_inout != nullptr));
     VO_TRY(vo_ensure_pinned(c, c->h_pose, sizeof(PoseState)));
     VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
-    if (mask_inout && n > 0)
-        VO_HIP(c, hipMemcpyAsync(mask_inout, c->d_pmask.p, n, hipMemcpyDeviceToHost, c->stream));
+    if (mask_inout && n > 0) VO_TRY(vo_xfer_out(c, mask_inout, c->d_pmask.p, n));
     if (pts4d && n > 0)
         for (int k = 0; k < 4; k++)
-            VO_HIP(c, hipMemcpyAsync(pts4d + (size_t)k * n, c->d_pts4.as<double>() + (size_t)k * n_cap,
-                                     (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+            VO_TRY(vo_xfer_out(c, pts4d + (size_t)k * n, c->d_pts4.as<double>() + (size_t)k * n_cap,
+                               (size_t)n * sizeof(double)));
+    VO_TRY(vo_xfer_finish(c));
     const PoseState* s = c->h_pose.as<PoseState>();
     memcpy(R, s->R, 9 * sizeof(double));
     memcpy(t, s->tt, 3 * sizeof(double));
@@ -283,19 +283,19 @@ int vo_triangulate(vo_ctx* c, const float* p0, const float* p1, int n, const dou
         return c->fail(VO_ERR_INVALID, "vo_triangulate: bad argument");
     if (n == 0) return VO_OK;  // the reference returns an empty vector (triangulation.cpp:49-51)
     VO_HIP(c, hipSetDevice(c->device));
+    VO_TRY(vo_xfer_begin(c));
     VO_TRY(upload_points(c, p0, p1, n));
     VO_TRY(vo_ensure(c, c->d_proj, 24 * sizeof(double)));
     VO_TRY(vo_ensure(c, c->d_pts4, (size_t)n * 3 * sizeof(double)));
     double P[24];
     memcpy(P, P0, 12 * sizeof(double));
     memcpy(P + 12, P1, 12 * sizeof(double));
-    VO_HIP(c, hipMemcpyAsync(c->d_proj.p, P, sizeof(P), hipMemcpyHostToDevice, c->stream));
+    VO_TRY(vo_xfer_in(c, c->d_proj.p, P, sizeof(P)));
     launch_triangulate(c->stream, c->d_proj.as<double>(), c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), n,
                        c->d_pts4.as<double>());
     VO_TRY(vo_check_launch(c, "triangulate"));
-    VO_HIP(c, hipMemcpyAsync(pts3d, c->d_pts4.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
-    return VO_OK;
+    VO_TRY(vo_xfer_out(c, pts3d, c->d_pts4.p, (size_t)n * 3 * sizeof(double)));
+    return vo_xfer_finish(c);
 }
 
 }  // extern "C"

@@ -83,6 +83,7 @@ int vo_lk_track(vo_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int 
         (n > 0 && (!prev_pts || !next_pts || !status)))
         return c->fail(VO_ERR_INVALID, "vo_lk_track: bad argument or unsupported tracker parameter");
     VO_HIP(c, hipSetDevice(c->device));
+    VO_TRY(vo_xfer_begin(c));
     VO_TRY(track_setup(c, w, h, prm));
     int si, sj;
     if (prev) {
@@ -103,7 +104,7 @@ int vo_lk_track(vo_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int 
         VO_TRY(vo_ensure(c, c->d_fp0, (size_t)n * sizeof(float2)));
         VO_TRY(vo_ensure(c, c->d_fp1, (size_t)n * sizeof(float2)));
         VO_TRY(vo_ensure(c, c->d_mask, (size_t)n));
-        VO_HIP(c, hipMemcpyAsync(c->d_fp0.p, prev_pts, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        VO_TRY(vo_xfer_in(c, c->d_fp0.p, prev_pts, (size_t)n * sizeof(float2)));
         LkArgs a;
         a.win_w = prm->win_w;
         a.win_h = prm->win_h;
@@ -116,10 +117,10 @@ int vo_lk_track(vo_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int 
                         c->d_tk_pyr[sj].as<uint8_t>(), c->d_fp0.as<float2>(), c->d_fp1.as<float2>(),
                         c->d_mask.as<uint8_t>(), n, a);
         VO_TRY(vo_check_launch(c, "tracker"));
-        VO_HIP(c, hipMemcpyAsync(next_pts, c->d_fp1.p, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
-        VO_HIP(c, hipMemcpyAsync(status, c->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        VO_TRY(vo_xfer_out(c, next_pts, c->d_fp1.p, (size_t)n * sizeof(float2)));
+        VO_TRY(vo_xfer_out(c, status, c->d_mask.p, (size_t)n));
     }
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_TRY(vo_xfer_finish(c));
     c->tk_last = sj;
     return VO_OK;
 }
