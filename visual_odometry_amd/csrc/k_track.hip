@@ -219,6 +219,184 @@ __global__ __launch_bounds__(256) void k_lk_track(TrackGeom g, const uint8_t* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same tracker for windows of at most 64 x LK_K pixels (the default 21 x 21 needs 7 per lane): a lane
+// keeps its window samples of I, Ix, Iy in registers (no LDS), the pixel offsets of its items are
+// computed once per level instead of a division per sample, all loads of a pass are issued before the
+// first is used, products are 24-bit multiplies, and the wave sums are two 32-bit DPP reductions (low and
+// high halves of the per-lane sums) instead of 64-bit shuffles.  Integer sums and float expressions are
+// those of the generic kernel, so the results are identical.
+// ---------------------------------------------------------------------------------------------
+#define LK_K 8
+
+namespace {
+
+__device__ __forceinline__ int lk_row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);  // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);  // row_ror:1
+    return v;
+}
+
+// exact sum over the wave of per-lane int32 values (the total may need more than 32 bits)
+__device__ __forceinline__ long long lk_wave_sum(int v) {
+    const int lo = lk_row16_sum(v & 0xffff), hi = lk_row16_sum(v >> 16);
+    const int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) +
+                    __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
+    const int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) +
+                    __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
+    return (long long)shi * 65536 + slo;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_lk_track_small(TrackGeom g, const uint8_t* __restrict__ pyrI,
+                                                        const short2* __restrict__ deriv,
+                                                        const uint8_t* __restrict__ pyrJ,
+                                                        const float2* __restrict__ prev_pts,
+                                                        float2* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                        int n, LkArgs a) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wv;
+    if (pt >= n) return;  // a whole wave leaves; the kernel has no block-wide barrier
+    const int ww = a.win_w, wh = a.win_h, area = ww * wh;
+    int iy[LK_K], ix[LK_K];
+    bool live[LK_K];
+#pragma unroll
+    for (int k = 0; k < LK_K; k++) {
+        const int i = lane + 64 * k;
+        live[k] = i < area;
+        iy[k] = live[k] ? i / ww : 0;
+        ix[k] = live[k] ? i - iy[k] * ww : 0;
+    }
+    const float2 p = prev_pts[pt];
+    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const long long cn = a.channels;
+    float2 np = make_float2(0.f, 0.f);
+    bool ok = true;
+    for (int level = g.nlevels - 1; level >= 0; level--) {
+        const TrackLevel L = g.lv[level];
+        const float sc = __int_as_float((127 - level) << 23);  // (float)(1. / (1 << level))
+        float px = p.x * sc, py = p.y * sc;
+        if (level == g.nlevels - 1) np = make_float2(px, py);
+        else np = make_float2(np.x * 2.f, np.y * 2.f);
+        px -= half_x;
+        py -= half_y;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -ww || ipx >= L.w || ipy < -wh || ipy >= L.h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float fa = px - ipx, fb = py - ipy;
+        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        const int pitch = L.pitch;
+        int off[LK_K];
+#pragma unroll
+        for (int k = 0; k < LK_K; k++) off[k] = __mul24(iy[k], pitch) + ix[k];
+        int Iw[LK_K], Dx[LK_K], Dy[LK_K];
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per lane: <= LK_K terms below 2^25
+        {
+            const uint8_t* I0 = tk_px(pyrI, L) + (ptrdiff_t)ipy * pitch + ipx;
+            const short2* D0 = deriv + L.offset + (size_t)(ipy + TK_PAD) * pitch + TK_PAD + ipx;
+            int sv[LK_K][4];
+            short2 dv[LK_K][4];
+#pragma unroll
+            for (int k = 0; k < LK_K; k++) {
+                const uint8_t* s = I0 + off[k];
+                const short2* d = D0 + off[k];
+                sv[k][0] = s[0], sv[k][1] = s[1], sv[k][2] = s[pitch], sv[k][3] = s[pitch + 1];
+                dv[k][0] = d[0], dv[k][1] = d[1], dv[k][2] = d[pitch], dv[k][3] = d[pitch + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < LK_K; k++) {
+                const int ival = TK_DESCALE(__mul24(sv[k][0], iw00) + __mul24(sv[k][1], iw01) +
+                                                __mul24(sv[k][2], iw10) + __mul24(sv[k][3], iw11),
+                                            W_BITS - 5);
+                int ixval = TK_DESCALE(__mul24((int)dv[k][0].x, iw00) + __mul24((int)dv[k][1].x, iw01) +
+                                           __mul24((int)dv[k][2].x, iw10) + __mul24((int)dv[k][3].x, iw11),
+                                       W_BITS);
+                int iyval = TK_DESCALE(__mul24((int)dv[k][0].y, iw00) + __mul24((int)dv[k][1].y, iw01) +
+                                           __mul24((int)dv[k][2].y, iw10) + __mul24((int)dv[k][3].y, iw11),
+                                       W_BITS);
+                if (!live[k]) ixval = iyval = 0;  // items past the window add nothing anywhere below
+                Iw[k] = ival;
+                Dx[k] = ixval;
+                Dy[k] = iyval;
+                sA11 += __mul24(ixval, ixval);
+                sA12 += __mul24(ixval, iyval);
+                sA22 += __mul24(iyval, iyval);
+            }
+        }
+        const long long iA11 = lk_wave_sum(sA11), iA12 = lk_wave_sum(sA12), iA22 = lk_wave_sum(sA22);
+        const float A11 = __ll2float_rn(iA11 * cn) * FLT_SCALE, A12 = __ll2float_rn(iA12 * cn) * FLT_SCALE,
+                    A22 = __ll2float_rn(iA22 * cn) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
+        if (minEig < a.min_eig || D < 1.1920928955078125e-07F) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.f / D;
+        const uint8_t* Jb = tk_px(pyrJ, L);
+        float nx = np.x - half_x, ny = np.y - half_y;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_count; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -ww || inx >= L.w || iny < -wh || iny >= L.h) {
+                if (level == 0) ok = false;
+                break;
+            }
+            fa = nx - inx;
+            fb = ny - iny;
+            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+            iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            const uint8_t* J0 = Jb + (ptrdiff_t)iny * pitch + inx;
+            int sv[LK_K][4];
+#pragma unroll
+            for (int k = 0; k < LK_K; k++) {
+                const uint8_t* s = J0 + off[k];
+                sv[k][0] = s[0], sv[k][1] = s[1], sv[k][2] = s[pitch], sv[k][3] = s[pitch + 1];
+            }
+            int sb1 = 0, sb2 = 0;  // per lane: <= LK_K terms below 2^26
+#pragma unroll
+            for (int k = 0; k < LK_K; k++) {
+                const int diff = TK_DESCALE(__mul24(sv[k][0], iw00) + __mul24(sv[k][1], iw01) +
+                                                __mul24(sv[k][2], iw10) + __mul24(sv[k][3], iw11),
+                                            W_BITS - 5) -
+                                 Iw[k];
+                sb1 += __mul24(diff, Dx[k]);
+                sb2 += __mul24(diff, Dy[k]);
+            }
+            const long long ib1 = lk_wave_sum(sb1), ib2 = lk_wave_sum(sb2);
+            const float b1 = __ll2float_rn(ib1 * cn) * FLT_SCALE, b2 = __ll2float_rn(ib2 * cn) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx;
+            ny += dy;
+            np = make_float2(nx + half_x, ny + half_y);
+            if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
+            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                np.x -= dx * 0.5f;
+                np.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+    }
+    if (lane == 0) {
+        next_pts[pt] = np;
+        status[pt] = ok ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr) {
@@ -246,6 +424,11 @@ void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, co
                      const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
                      const LkArgs& a) {
     if (n <= 0) return;
+    if (a.win_w * a.win_h <= 64 * LK_K) {
+        hipLaunchKernelGGL(k_lk_track_small, dim3(cdiv(n, 4)), dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts,
+                           next_pts, status, n, a);
+        return;
+    }
     const size_t lds = (size_t)4 * a.win_w * a.win_h * 3 * sizeof(int16_t);
     hipLaunchKernelGGL(k_lk_track, dim3(cdiv(n, 4)), dim3(256), lds, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts,
                        status, n, a);
