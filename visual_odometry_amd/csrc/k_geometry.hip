@@ -209,15 +209,60 @@ __global__ __launch_bounds__(64) void k_replay(int h0, int h1, EstState* __restr
     }
 }
 
-// LMedS: median of the float Sampson errors of one model, by bitwise selection on the error bit
-// patterns held in LDS (non-negative floats order like unsigned integers).
+// LMedS: median of the float Sampson errors of one model.  Non-negative floats order like unsigned
+// integers, so the median is a radix selection on the error bit patterns held in LDS: four passes of
+// eight bits, each a 256-bin histogram (LDS atomics) of the elements that still match the prefix, a wave
+// scan of the bins and a step into the bin that holds the wanted rank.  One wave per model.
+namespace {
+
+// k-th smallest (0-based) of e[0..n): every lane returns it
+__device__ uint32_t wave_radix_select(const uint32_t* e, int n, int k, uint32_t* hist, int lane) {
+    uint32_t prefix = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t v = e[i];
+            if (shift == 24 || (v >> (shift + 8)) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];  // bins 4 lane .. 4 lane + 3
+        const int t = (int)(h.x + h.y + h.z + h.w);
+        int inc = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        const int owner = __ffsll((long long)__ballot(inc > k)) - 1;  // first lane whose bins reach rank k
+        const int ex = __shfl(inc - t, owner);
+        const uint32_t hx = __shfl(h.x, owner), hy = __shfl(h.y, owner), hz = __shfl(h.z, owner);
+        int r = k - ex, b = 4 * owner;
+        if (r >= (int)hx) {
+            r -= hx, b++;
+            if (r >= (int)hy) {
+                r -= hy, b++;
+                if (r >= (int)hz) r -= hz, b++;
+            }
+        }
+        k = r;
+        prefix = (prefix << 8) | (uint32_t)b;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return prefix;
+}
+
+}  // namespace
+
 __global__ __launch_bounds__(256) void k_lmeds_medians(const EstState* __restrict__ st,
                                                        const double2* __restrict__ x1,
                                                        const double2* __restrict__ x2, int n_cap,
                                                        const double* __restrict__ models,
                                                        const int* __restrict__ nmodels,
                                                        double* __restrict__ medians, int H) {
-    extern __shared__ uint32_t errs[];  // 4 waves x n_cap
+    extern __shared__ uint32_t errs[];  // 4 waves x (n_cap errors + 256 bins)
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int idx = blockIdx.x * 4 + wv;
@@ -227,7 +272,9 @@ __global__ __launch_bounds__(256) void k_lmeds_medians(const EstState* __restric
     const size_t slot = (size_t)pair * H + h;
     if (m >= nmodels[slot]) return;
     const int n = s.n;
-    uint32_t* e = errs + (size_t)wv * n_cap;
+    const int ecap = (n_cap + 3) & ~3;
+    uint32_t* e = errs + (size_t)wv * (ecap + 256);
+    uint32_t* hist = e + ecap;  // 16-byte aligned
     double E[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) E[k] = models[slot * 90 + 9 * m + k];
@@ -235,21 +282,29 @@ __global__ __launch_bounds__(256) void k_lmeds_medians(const EstState* __restric
         const double2 u = x1[(size_t)pair * n_cap + i], v = x2[(size_t)pair * n_cap + i];
         e[i] = __float_as_uint(sampson_error(E, u.x, u.y, v.x, v.y));
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // k-th smallest (0-based) for k = n/2 and, for even n, n/2 - 1
-    const int kb = n / 2, ka = (n & 1) ? kb : kb - 1;
-    uint32_t ra = 0, rb = 0;
-    for (int bit = 31; bit >= 0; bit--) {
-        const uint32_t ca = ra | (1u << bit), cb = rb | (1u << bit);
-        int na = 0, nb = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const uint32_t v = i < n ? e[i] : 0xffffffffu;
-            na += __popcll(__ballot(v < ca));
-            nb += __popcll(__ballot(v < cb));
+    // upper median = the (n/2)-th smallest; for even n the lower one is the largest element below it
+    // unless the upper median's value also occupies rank n/2 - 1
+    const int kb = n / 2;
+    const uint32_t rb = wave_radix_select(e, n, kb, hist, lane);
+    uint32_t ra = rb;
+    if (!(n & 1)) {
+        int below = 0;
+        uint32_t mx = 0;
+        for (int i = lane; i < n; i += 64) {
+            const uint32_t v = e[i];
+            if (v < rb) {
+                below++;
+                mx = max(mx, v);
+            }
         }
-        if (na <= ka) ra = ca;
-        if (nb <= kb) rb = cb;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            below += __shfl_xor(below, o);
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        if (below == kb) ra = mx;  // rank n/2 - 1 is the largest of the elements below
     }
     if (lane == 0) {
         const float fa = __uint_as_float(ra), fb = __uint_as_float(rb);
@@ -532,7 +587,10 @@ void launch_replay(hipStream_t st, int h0, int h1, EstState* s, const int* nmode
 
 void launch_lmeds(hipStream_t st, EstState* s, const double2* x1, const double2* x2, int n_cap, const double* models,
                   const int* nmodels, double* medians, int H, int niters, int npairs) {
-    const size_t lds = (size_t)4 * n_cap * sizeof(uint32_t);
+    const size_t lds = (size_t)4 * (((n_cap + 3) & ~3) + 256) * sizeof(uint32_t);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lmeds_medians),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lmeds_medians, dim3(cdiv(niters * 10, 4), npairs), dim3(256), lds, st, s, x1, x2, n_cap,
                        models, nmodels, medians, H);
     hipLaunchKernelGGL(k_lmeds_select, dim3(npairs), dim3(64), 0, st, s, nmodels, medians, H);
