@@ -128,6 +128,30 @@ def test_orb_full_hd_frame(oracle, frames):
     assert len(fo) > 5000 and np.array_equal(kf, fo)
 
 
+def test_orb_more_corners_than_the_candidate_list(oracle):
+    # a noise image has more FAST corners per frame (~78 k) than the initial candidate list (65 536): the
+    # list grows and the frame goes through the host selection; cv has no such limit
+    from visual_odometry_amd import api
+
+    img = _noise(376, 1241, 24, smooth=True)
+    ctx = api.VoContext(0)
+    try:
+        kg, dg = ctx.orb_detect_compute(img, api.orb_params(2000, edge_threshold=19))
+        assert ctx.get_option(api.OPT_LAST_FLAGS) & 1  # the device selection handed the frame over
+        kf = ctx.fast_detect(img, 20, True, cap=400000)
+        # and a frame with few corners afterwards on the same (grown) context
+        img2 = _noise(200, 320, 77, smooth=True)
+        kg2, dg2 = ctx.orb_detect_compute(img2, api.orb_params(300, nlevels=3))
+    finally:
+        ctx.close()
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(2000, edge_threshold=19))
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    fo = oracle.fast_detect(img, 20, True)
+    assert np.array_equal(kf, fo)
+    ko2, do2 = oracle.orb_detect_compute(img2, oracle.orb_params(300, nlevels=3))
+    assert np.array_equal(kg2, ko2) and np.array_equal(dg2, do2)
+
+
 def test_orb_flat_image_gives_nothing(vo, oracle):
     from visual_odometry_amd import api
 

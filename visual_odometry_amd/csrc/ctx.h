@@ -85,7 +85,8 @@ struct vo_ctx {
         size_t offset, bytes;
     };
     std::vector<XferOut> xfer_out;
-    int max_cand = 65536;
+    int max_cand = 65536;  // candidates per frame the lists hold; grows when a frame has more
+    int cand_nms = 1;      // nms flag of the last detection (to rewrite the lists after growing)
     int last_flags = 0;  // OR of the VO_SEL_* flags of the last batch
     int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
     int kp_cap = 0;

@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
     const int e = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l + 1], max_cand);
     int n = e - b;
     int* cnt = selcnt + (size_t)f * VO_ORB_MAX_LEVELS + l;
+    // a frame with more candidates than its list holds was truncated: the host path regrows the list
+    if (l == 0 && tid == 0 && lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + g->nlevels] > max_cand)
+        atomicOr(&flags[f], VO_SEL_OVERSIZE);
     if (n > sel_cap) {
         if (tid == 0) {
             atomicOr(&flags[f], VO_SEL_OVERSIZE);

@@ -264,23 +264,41 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
                     nframes);
     launch_cand_write(st, dg, g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
                       c->d_score.as<uint8_t>(), nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
+    c->cand_nms = nms;
     return vo_check_launch(c, "feature detection");
+}
+
+// Level offsets to the host; when a frame has more FAST corners than the candidate lists hold (cv has no
+// such limit) the lists grow and are written again from the mask table, segment bases and score map,
+// which are complete.  Synchronises.
+static int feat_cand_capacity(vo_ctx* c, int nframes) {
+    const PyrGeom& g = c->geom;
+    hipStream_t st = c->stream;
+    const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
+    VO_HIP(c, hipMemcpyAsync(c->h_lvlofs.p, c->d_lvlofs.p, lv_bytes, hipMemcpyDeviceToHost, st));
+    VO_HIP(c, hipStreamSynchronize(st));
+    const int* lv = c->h_lvlofs.as<int>();
+    int most = 0;
+    for (int f = 0; f < nframes; f++) most = std::max(most, lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels]);
+    if (most <= c->max_cand) return VO_OK;
+    const size_t nf = (size_t)c->feat_frames;
+    c->max_cand = (most + 65535) & ~65535;
+    VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
+    VO_TRY(vo_ensure(c, c->d_selidx, nf * c->max_cand * sizeof(int)));
+    launch_cand_write(st, c->d_geom.as<PyrGeom>(), g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
+                      c->d_score.as<uint8_t>(), c->cand_nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
+    return vo_check_launch(c, "candidate lists");
 }
 
 // Candidate lists to the host (plain FAST output, host selection path).  Synchronises.
 int feat_fetch_cands(vo_ctx* c, int nframes) {
     const PyrGeom& g = c->geom;
     hipStream_t st = c->stream;
+    VO_TRY(feat_cand_capacity(c, nframes));
     VO_TRY(vo_ensure_pinned(c, c->h_cand, (size_t)nframes * c->max_cand * sizeof(Cand)));
-    const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
-    VO_HIP(c, hipMemcpyAsync(c->h_lvlofs.p, c->d_lvlofs.p, lv_bytes, hipMemcpyDeviceToHost, st));
-    VO_HIP(c, hipStreamSynchronize(st));
     const int* lv = c->h_lvlofs.as<int>();
     for (int f = 0; f < nframes; f++) {
         const int total = lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels];
-        if (total > c->max_cand)
-            return c->fail(VO_ERR_CAPACITY, "frame %d has %d FAST candidates, workspace holds %d", f, total,
-                           c->max_cand);
         if (total > 0)
             VO_HIP(c, hipMemcpyAsync(c->h_cand.as<Cand>() + (size_t)f * c->max_cand,
                                      c->d_cand.as<Cand>() + (size_t)f * c->max_cand, (size_t)total * sizeof(Cand),
@@ -309,6 +327,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
 // on host threads, upload of the selected keypoints.  Synchronises.
 int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     const PyrGeom& g = c->geom;
+    VO_TRY(feat_cand_capacity(c, nframes));  // before Harris: a regrown list starts without responses
     launch_harris(c->stream, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->d_lvlofs.as<int>(),
                   c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
     VO_TRY(vo_check_launch(c, "harris"));
