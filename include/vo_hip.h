@@ -206,6 +206,7 @@ int vo_prof_enable(vo_ctx* ctx, int on);
  * (0 = every frame was selected on the device). */
 #define VO_OPT_SEL_CAP 0
 #define VO_OPT_LAST_FLAGS 1
+#define VO_OPT_CAND_CAP 2 /* read only: FAST candidates per frame the lists hold now (they grow on demand) */
 int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
 int vo_ctx_get_option(vo_ctx* ctx, int option, int* value);
 

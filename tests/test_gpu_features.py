@@ -138,6 +138,7 @@ def test_orb_more_corners_than_the_candidate_list(oracle):
     try:
         kg, dg = ctx.orb_detect_compute(img, api.orb_params(2000, edge_threshold=19))
         assert ctx.get_option(api.OPT_LAST_FLAGS) & 1  # the device selection handed the frame over
+        assert ctx.get_option(api.OPT_CAND_CAP) > 65536  # the lists grew
         kf = ctx.fast_detect(img, 20, True, cap=400000)
         # and a frame with few corners afterwards on the same (grown) context
         img2 = _noise(200, 320, 77, smooth=True)

@@ -81,6 +81,41 @@ def test_pairs_run_equals_single_calls(vo, frames):
     assert np.array_equal(E, E_b) and np.array_equal(m, m1_b)
 
 
+def test_pairs_run_frames_with_more_corners_than_the_candidate_list():
+    """Noise frames (~78 k FAST corners per pyramid at edge threshold 19 and FAST threshold 10) overflow
+    the initial candidate lists: the batch goes through the host selection with grown lists and still
+    equals the single calls."""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (376, 1241 + 8)).astype(np.float32)
+    k = np.ones(3, np.float32) / 3
+    base = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, base)
+    base = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, base)
+    fr = np.ascontiguousarray(np.stack([base[:, s:s + 1241] for s in (0, 3, 6)]).astype(np.uint8))  # shifted copies
+    ctx = api.VoContext(0)
+    try:
+        d = torch.from_numpy(fr).to("cuda:0")
+        torch.cuda.synchronize()
+        prm = api.pair_params(1000)
+        prm.orb.edge_threshold = 19
+        prm.orb.fast_threshold = 10
+        res = ctx.pairs_run_dev(d.data_ptr(), 3, 1241, 376, 1241, 1241 * 376, K, prm)
+        assert ctx.get_option(api.OPT_LAST_FLAGS) & 1
+        assert ctx.get_option(api.OPT_CAND_CAP) > 65536  # the lists grew
+        k0, d0 = ctx.pairs_get_frame(0)
+        k1, d1 = ctx.pairs_get_frame(1)
+        good_b, _, _ = ctx.pairs_get_matches(0)
+        sk0, sd0 = ctx.orb_detect_compute(fr[0], api.orb_params(1000, edge_threshold=19, fast_threshold=10))
+        sk1, sd1 = ctx.orb_detect_compute(fr[1], api.orb_params(1000, edge_threshold=19, fast_threshold=10))
+        assert len(sk0) > 900
+        assert np.array_equal(k0, sk0) and np.array_equal(d0, sd0)
+        assert np.array_equal(k1, sk1) and np.array_equal(d1, sd1)
+        knn, nv = ctx.knn2_hamming(sd0, sd1)
+        good = ctx.match_filter(knn, nv, sk0, sk1)
+        assert np.array_equal(good, good_b) and res[0].n_good == len(good)
+    finally:
+        ctx.close()
+
+
 def test_pairs_run_flat_frames(vo):
     """No keypoints anywhere: every pair reports status VO_ERR_FAILED and zero counts."""
     fr = np.full((3, 376, 1241), 77, np.uint8)

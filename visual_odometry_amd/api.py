@@ -17,7 +17,7 @@ KP_DTYPE = np.dtype(
 DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
 
 LMEDS, RANSAC = 4, 8
-OPT_SEL_CAP, OPT_LAST_FLAGS = 0, 1
+OPT_SEL_CAP, OPT_LAST_FLAGS, OPT_CAND_CAP = 0, 1, 2
 VO_OK, VO_ERR_INVALID, VO_ERR_CAPACITY, VO_ERR_DEVICE, VO_ERR_FAILED = 0, 1, 2, 3, 4
 
 

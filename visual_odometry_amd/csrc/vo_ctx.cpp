@@ -231,6 +231,7 @@ int vo_ctx_get_option(vo_ctx* c, int option, int* value) {
     if (!c || !value) return VO_ERR_INVALID;
     if (option == VO_OPT_SEL_CAP) *value = c->sel_cap;
     else if (option == VO_OPT_LAST_FLAGS) *value = c->last_flags;
+    else if (option == VO_OPT_CAND_CAP) *value = c->max_cand;
     else return c->fail(VO_ERR_INVALID, "unknown option %d", option);
     return VO_OK;
 }
