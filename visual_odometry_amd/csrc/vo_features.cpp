@@ -503,9 +503,10 @@ int vo_orb_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int stri
     *n = cnt;
     if (cnt > cap) return c->fail(VO_ERR_CAPACITY, "vo_orb_detect_compute: %d keypoints, capacity %d", cnt, cap);
     if (cnt == 0) return VO_OK;
-    if (kp) VO_HIP(c, hipMemcpyAsync(kp, c->d_kp.p, (size_t)cnt * sizeof(vo_keypoint), hipMemcpyDeviceToHost, c->stream));
-    if (desc) VO_HIP(c, hipMemcpyAsync(desc, c->d_desc.p, (size_t)cnt * 32, hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_TRY(vo_xfer_begin(c));
+    if (kp) VO_TRY(vo_xfer_out(c, kp, c->d_kp.p, (size_t)cnt * sizeof(vo_keypoint)));
+    if (desc) VO_TRY(vo_xfer_out(c, desc, c->d_desc.p, (size_t)cnt * 32));
+    VO_TRY(vo_xfer_finish(c));
     return VO_OK;
 }
 

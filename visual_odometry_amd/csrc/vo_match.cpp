@@ -84,11 +84,12 @@ int vo_knn2_hamming(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     if (nq == 0) return VO_OK;
     const int row = desc_bytes <= 32 ? 32 : 64;  // rows zero-padded to 32 or 64 bytes
     const int words = row / 4;
+    VO_TRY(vo_xfer_begin(c));
     VO_TRY(vo_ensure(c, c->d_q, (size_t)nq * row));
     VO_TRY(vo_ensure(c, c->d_t, (size_t)std::max(nt, 1) * row));
     if (desc_bytes == row) {
-        VO_HIP(c, hipMemcpyAsync(c->d_q.p, q, (size_t)nq * row, hipMemcpyHostToDevice, c->stream));
-        if (nt) VO_HIP(c, hipMemcpyAsync(c->d_t.p, t, (size_t)nt * row, hipMemcpyHostToDevice, c->stream));
+        VO_TRY(vo_xfer_in(c, c->d_q.p, q, (size_t)nq * row));
+        if (nt) VO_TRY(vo_xfer_in(c, c->d_t.p, t, (size_t)nt * row));
     } else {
         VO_HIP(c, hipMemsetAsync(c->d_q.p, 0, (size_t)nq * row, c->stream));
         VO_HIP(c, hipMemcpy2DAsync(c->d_q.p, row, q, desc_bytes, desc_bytes, nq, hipMemcpyHostToDevice, c->stream));
@@ -100,7 +101,7 @@ int vo_knn2_hamming(vo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int n
     VO_TRY(match_knn2_dev(c, c->d_q.as<uint32_t>(), c->d_t.as<uint32_t>(), 0, 0, nullptr, nq, nt, words, 1, nq));
     VO_TRY(vo_ensure_pinned(c, c->h_knn, (size_t)nq * sizeof(uint2)));
     VO_HIP(c, hipMemcpyAsync(c->h_knn.p, c->d_knn.p, (size_t)nq * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_TRY(vo_xfer_finish(c));
     const uint2* k = c->h_knn.as<uint2>();
     for (int i = 0; i < nq; i++) {
         const uint32_t key[2] = {k[i].x, k[i].y};
@@ -160,10 +161,10 @@ int vo_match_filter(vo_ctx* c, const vo_dmatch* knn, const int* n_valid, int nq,
     VO_TRY(vo_ensure(c, c->d_knn, (size_t)nq * sizeof(uint2)));
     VO_TRY(vo_ensure(c, c->d_kq, (size_t)nkq * sizeof(vo_keypoint)));
     VO_TRY(vo_ensure(c, c->d_kt, (size_t)std::max(nkt, 1) * sizeof(vo_keypoint)));
-    VO_HIP(c, hipMemcpyAsync(c->d_knn.p, k, (size_t)nq * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->d_kq.p, kq, (size_t)nkq * sizeof(vo_keypoint), hipMemcpyHostToDevice, c->stream));
-    if (nkt > 0)
-        VO_HIP(c, hipMemcpyAsync(c->d_kt.p, kt, (size_t)nkt * sizeof(vo_keypoint), hipMemcpyHostToDevice, c->stream));
+    VO_TRY(vo_xfer_begin(c));
+    VO_HIP(c, hipMemcpyAsync(c->d_knn.p, k, (size_t)nq * sizeof(uint2), hipMemcpyHostToDevice, c->stream));  // pinned
+    VO_TRY(vo_xfer_in(c, c->d_kq.p, kq, (size_t)nkq * sizeof(vo_keypoint)));
+    if (nkt > 0) VO_TRY(vo_xfer_in(c, c->d_kt.p, kt, (size_t)nkt * sizeof(vo_keypoint)));
     VO_TRY(match_filter_dev(c, c->d_kq.as<vo_keypoint>(), c->d_kt.as<vo_keypoint>(), 0, nullptr, nq, 1, nq, ratio,
                             max_disp));
     VO_TRY(vo_ensure_pinned(c, c->h_good, (size_t)nq * sizeof(GoodMatch) + sizeof(int)));
@@ -171,7 +172,7 @@ int vo_match_filter(vo_ctx* c, const vo_dmatch* knn, const int* n_valid, int nq,
     VO_HIP(c, hipMemcpyAsync(h_n, c->d_ngood.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(c->h_good.p, c->d_good.p, (size_t)nq * sizeof(GoodMatch), hipMemcpyDeviceToHost,
                              c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
+    VO_TRY(vo_xfer_finish(c));
     const GoodMatch* g = c->h_good.as<GoodMatch>();
     for (int i = 0; i < *h_n; i++) {
         good[i].queryIdx = g[i].q;
