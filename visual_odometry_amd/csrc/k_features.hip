@@ -675,8 +675,13 @@ struct RI {
 // All 256 threads call it with the same arguments.  Each wave lists the stops of its quarter of the
 // range in its own segment of Lp / Ra; the j-th stop overall is found through the four segment counts
 // (sh[0..7]), so the lists are never compacted.
+// MODE 0 also carries nth_element's pivot move: the caller has chosen v[piv] as the pivot and wants it
+// swapped with v[first - 1]; instead of two more barriers around that swap, pass 1 reads the value that
+// position piv will hold (sub_r, the old v[first - 1].r) from a register, and thread 0 performs the swap
+// in LDS after the first barrier, when nobody reads the old values any more.
 template <int MODE>
-__device__ int block_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int* sh, int tid) {
+__device__ int block_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int* sh, int tid,
+                               int piv = -1, float sub_r = 0.f) {
     const int wv = tid >> 6, lane = tid & 63;
     const int span = ((last - first + 255) >> 8) << 6;
     const int wb = first + wv * span, we = min(last, wb + span);
@@ -685,7 +690,8 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
     for (int i0 = wb; i0 < we; i0 += 64) {
         const int i = i0 + lane;
         const bool in = i < we;
-        const float r = in ? v[i].r : 0.f;
+        float r = in ? v[i].r : 0.f;
+        if (MODE == 0 && i == piv) r = sub_r;
         bool isL, isR;
         if (MODE == 0) {
             isL = in && !(r > key);   // the left pointer stops: !comp(*first, pivot)
@@ -705,6 +711,11 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
         sh[4 + wv] = nR;
     }
     __syncthreads();
+    if (MODE == 0 && piv >= 0 && tid == 0) {
+        const RI t = v[first - 1];
+        v[first - 1] = v[piv];
+        v[piv] = t;
+    }
     const int l0 = sh[0], l1 = l0 + sh[1], l2 = l1 + sh[2], nLt = l2 + sh[3];
     const int r0 = sh[4], r1 = r0 + sh[5], r2 = r1 + sh[6], nRt = r2 + sh[7];
     auto leftStop = [&](int k) -> int {  // k-th stop of the left pointer
@@ -720,9 +731,12 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
     };
     const int m = min(nLt, nRt);
     int Kw = 0;  // number of swaps: stops cross monotonically
+    int a0 = 0, b0 = 0;  // the thread's first pair of stops, kept for the swap below
     for (int k0 = 0; k0 < m; k0 += 256) {
         const int k = k0 + tid;
-        const bool ok = k < m && leftStop(k) < rightStop(k);
+        const int a = k < m ? leftStop(k) : 0, b = k < m ? rightStop(k) : 0;
+        if (k0 == 0) a0 = a, b0 = b;
+        const bool ok = k < m && a < b;
         Kw += __popcll(__ballot(ok));
     }
     if (lane == 0) sh[8 + wv] = Kw;
@@ -737,7 +751,7 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
         ret = first + nRt;
     }
     for (int k = tid; k < K; k += 256) {
-        const int a = leftStop(k), b = rightStop(k);
+        const int a = k == tid ? a0 : leftStop(k), b = k == tid ? b0 : rightStop(k);
         const RI t = v[a];
         v[a] = v[b];
         v[b] = t;
@@ -755,24 +769,18 @@ __device__ bool block_nth_element(RI* v, int first, int nth, int last, uint16_t*
         if (depth == 0) return false;
         depth--;
         const int mid = first + (last - first) / 2;
-        const float ra = v[first + 1].r, rb = v[mid].r, rc = v[last - 1].r;
+        const float ra = v[first + 1].r, rb = v[mid].r, rc = v[last - 1].r, rf = v[first].r;
         int sel;
+        float pivot;
         if (ra > rb) {
-            if (rb > rc) sel = mid;
-            else if (ra > rc) sel = last - 1;
-            else sel = first + 1;
-        } else if (ra > rc) sel = first + 1;
-        else if (rb > rc) sel = last - 1;
-        else sel = mid;
-        __syncthreads();
-        if (tid == 0) {
-            const RI t = v[first];
-            v[first] = v[sel];
-            v[sel] = t;
-        }
-        __syncthreads();
-        const float pivot = v[first].r;
-        const int cut = block_partition<0>(v, first + 1, last, pivot, Lp, Ra, sh, tid);
+            if (rb > rc) sel = mid, pivot = rb;
+            else if (ra > rc) sel = last - 1, pivot = rc;
+            else sel = first + 1, pivot = ra;
+        } else if (ra > rc) sel = first + 1, pivot = ra;
+        else if (rb > rc) sel = last - 1, pivot = rc;
+        else sel = mid, pivot = rb;
+        // std::iter_swap(first, sel) happens inside the partition (see there)
+        const int cut = block_partition<0>(v, first + 1, last, pivot, Lp, Ra, sh, tid, sel, rf);
         if (cut <= nth) first = cut;
         else last = cut;
     }
