@@ -62,7 +62,7 @@ struct vo_ctx {
     DevBuf d_segbase; // int [frame][segs_total]: candidate-list position of each segment's first keypoint
     DevBuf d_lvlofs;  // int [frame][VO_ORB_MAX_LEVELS + 1]
     DevBuf d_cand;    // Cand [frame][max_cand]: row-major candidates, level after level
-    DevBuf d_selidx;  // int [frame][max_cand]: device selection, level l's picks at lvlofs[l]
+    DevBuf d_selcand; // Cand [frame][max_cand]: device selection, level l's picks (copies) at lvlofs[l]
     DevBuf d_selcnt;  // int [frame][VO_ORB_MAX_LEVELS]
     DevBuf d_flags;   // int [frame]: VO_SEL_* flags of the device selection
     DevBuf d_sel;     // Cand [frame][kp_cap]: keypoints selected on the host (fallback path)

@@ -819,7 +819,7 @@ __device__ int block_retain_best(RI* v, int n, int n_points, uint16_t* Lp, uint1
 __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                     const int* __restrict__ lvlofs, Cand* __restrict__ cand,
                                                     int max_cand, Quotas quota, int sel_cap,
-                                                    int* __restrict__ selidx, int* __restrict__ selcnt,
+                                                    Cand* __restrict__ selcand, int* __restrict__ selcnt,
                                                     int* __restrict__ flags) {
     extern __shared__ unsigned char sel_smem[];
     __shared__ int sh[12];
@@ -885,7 +885,13 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         }
         return;
     }
-    for (int i = tid; i < n; i += 256) selidx[(size_t)f * max_cand + b + i] = v[i].idx;
+    // the picks are written out as copies, so that the next kernel reads a keypoint with one load
+    // instead of index -> candidate
+    for (int i = tid; i < n; i += 256) {
+        Cand cd = C[v[i].idx];
+        cd.harris = v[i].r;
+        selcand[(size_t)f * max_cand + b + i] = cd;
+    }
     if (tid == 0) *cnt = n;
 }
 
@@ -969,15 +975,27 @@ __device__ __forceinline__ int row16_sum(int v) {
 // with two accumulating v_dot4_u32_u8 per dword: m10 = sum((4k + j) b) - (15 + o) sum(b), m01 = v sum(b).
 // Integer sums: the same m10, m01 as a per-pixel loop.  Few dependent loads: the per-level counts and
 // offsets of the frame arrive together (uniform addresses), the level's geometry is fetched while the
-// selidx -> cand chain is in flight, the row and mask loads go out together.
+// keypoint copy is in flight, the row and mask loads go out together.
 __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   const Cand* __restrict__ sel, const Cand* __restrict__ cand,
-                                                  int max_cand, const int* __restrict__ selidx,
+                                                  int max_cand, const Cand* __restrict__ selcand,
                                                   const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
     const int f = blockIdx.y;
     const int n = nkp[f];
+    // the per-level counts and offsets travel with the keypoint count (uniform addresses, one batch of
+    // scalar loads), before the early exit that only needs the count
+    int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
+    {
+        const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
+        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+            cnt[i] = sc[i];
+            ofs[i] = lo[i];
+        }
+    }
     if ((int)(blockIdx.x * 8 + 2 * (threadIdx.x >> 6)) >= n) return;  // the whole wave
     const int k = min((int)(blockIdx.x * 8 + (threadIdx.x >> 5)), n - 1);
     const bool live = (int)(blockIdx.x * 8 + (threadIdx.x >> 5)) < n;
@@ -988,14 +1006,6 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
         cd = sel[(size_t)f * kp_cap + k];
         lg = cd.level;
     } else {
-        const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
-        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
-        int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
-#pragma unroll
-        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
-            cnt[i] = sc[i];
-            ofs[i] = lo[i];
-        }
         const int nl = g->nlevels;
         int l = 0, rem = k, base = 0;
         bool found = false;
@@ -1012,8 +1022,7 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
             }
         if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
         lg = l;
-        const int idx = selidx[(size_t)f * max_cand + base + rem];
-        cd = cand[(size_t)f * max_cand + idx];
+        cd = selcand[(size_t)f * max_cand + base + rem];
     }
     const int pitch = g->lv[lg].pitch;
     const unsigned lofs = g->lv[lg].offset;
@@ -1289,23 +1298,23 @@ void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, co
 }
 
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
-                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, int* selidx,
+                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
                        int* selcnt, int* flags, int* nkp, int n_bound, int nframes) {
     const size_t lds = (size_t)sel_cap * (sizeof(RI) + 2 * sizeof(uint16_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_select),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_orb_select, dim3(hg.nlevels, nframes), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
-                       max_cand, quota, sel_cap, selidx, selcnt, flags);
+                       max_cand, quota, sel_cap, selcand, selcnt, flags);
     hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
                        n_bound, nframes);
 }
 
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const Cand* cand,
-                     int max_cand, const int* selidx, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes) {
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, 8), nframes);
-    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, cand, max_cand, selidx, selcnt, lvlofs,
+    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, cand, max_cand, selcand, selcnt, lvlofs,
                        nkp, kp_cap, out);
 }
 

@@ -106,10 +106,10 @@ void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
 void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
                    int max_cand, int grid_cand, int nframes);
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
-                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, int* selidx,
+                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
                        int* selcnt, int* flags, int* nkp, int n_bound, int nframes);
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const Cand* cand,
-                     int max_cand, const int* selidx, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes);
 void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
                    const Taps7& taps, int nlevels_used, int nframes);

@@ -180,7 +180,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_masks, &c->d_segbase, &c->d_selidx, &c->d_selcnt, &c->d_flags,
+    DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_masks, &c->d_segbase, &c->d_selcand, &c->d_selcnt, &c->d_flags,
                      &c->d_lvlofs, &c->d_cand,  &c->d_sel,   &c->d_coef,   &c->d_geom,   &c->d_kp,
                      &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,
                      &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,

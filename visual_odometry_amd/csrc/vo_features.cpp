@@ -227,7 +227,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     VO_TRY(vo_ensure(c, c->d_segbase, nf * c->geom.segs_total * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
-    VO_TRY(vo_ensure(c, c->d_selidx, nf * c->max_cand * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_selcand, nf * c->max_cand * sizeof(Cand)));
     VO_TRY(vo_ensure(c, c->d_selcnt, nf * VO_ORB_MAX_LEVELS * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_flags, (nf + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_sel, nf * kp_cap * sizeof(Cand)));
@@ -284,7 +284,7 @@ static int feat_cand_capacity(vo_ctx* c, int nframes) {
     const size_t nf = (size_t)c->feat_frames;
     c->max_cand = (most + 65535) & ~65535;
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
-    VO_TRY(vo_ensure(c, c->d_selidx, nf * c->max_cand * sizeof(int)));
+    VO_TRY(vo_ensure(c, c->d_selcand, nf * c->max_cand * sizeof(Cand)));
     launch_cand_write(st, c->d_geom.as<PyrGeom>(), g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
                       c->d_score.as<uint8_t>(), c->cand_nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
     return vo_check_launch(c, "candidate lists");
@@ -317,7 +317,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) q.q[l] = l < c->geom.nlevels ? c->quota[l] : 0;
     VO_HIP(c, hipMemsetAsync(c->d_flags.p, 0, (size_t)(nframes + 1) * sizeof(int), st));
     launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom, c->d_lvlofs.as<int>(),
-                      c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selidx.as<int>(), c->d_selcnt.as<int>(),
+                      c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                       c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes);
     return vo_check_launch(c, "keypoint selection");
 }
@@ -390,7 +390,7 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
-                        c->d_cand.as<Cand>(), c->max_cand, c->d_selidx.as<int>(), c->d_selcnt.as<int>(),
+                        c->d_cand.as<Cand>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                         c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                         nframes);
     launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
