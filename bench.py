@@ -126,14 +126,23 @@ def main():
 
     import torch
 
+    # VO_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path
+    # (barriers, max over ranks, trajectory gather, rank-0 report) on a one-GPU box.  Not a measurement.
+    rehearse = os.environ.get("VO_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev  # where the collectives' tensors live
 
     from visual_odometry_amd import api, shard
 
@@ -163,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     seq_stats = seq.stats()
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     pairs_per_step = n - 1
@@ -172,7 +181,7 @@ def main():
     # ---- chain the relative poses into a trajectory on the host, gather over RCCL --------------
     traj = shard.chain_poses([(res[p].status, np.array(res[p].R), np.array(res[p].t)) for p in range(n - 1)], n)
     if dist is not None:
-        all_traj = shard.gather_trajectories({rank: traj}, dist, dev)
+        all_traj = shard.gather_trajectories({rank: traj}, dist, cdev)
         torch.cuda.synchronize()
         assert len(all_traj) == world
 
