@@ -78,6 +78,12 @@ struct vo_ctx {
     // the caller's pageable memory blocks the host for ~30 us each, a pinned one is queued in ~5.  Inputs
     // are copied into the arena and sent asynchronously; outputs land in the arena and vo_xfer_finish
     // (synchronise + copy out) hands them to the caller.  The arena is recycled at every finish.
+    DevBuf d_pack;       // result tables of a batch gathered for one device -> host copy
+    PinnedBuf h_pack;
+    size_t pack_at[5] = {0, 0, 0, 0, 0}, pack_bytes[5] = {0, 0, 0, 0, 0};
+    double cam_cache[4] = {0, 0, 0, 0};  // camera table on the device: K it was built from, pairs it covers
+    int cam_pairs = 0;
+    const void* cam_ptr = nullptr;
     PinnedBuf h_xfer;
     size_t xfer_used = 0;
     struct XferOut {

@@ -612,6 +612,20 @@ void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps
                        pts4);
 }
 
+__global__ __launch_bounds__(256) void k_pack_results(PackArgs a, uint32_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+        const int j = i - a.at[t];
+        if (j >= 0 && j < a.ndw[t]) out[i] = a.src[t][j];
+    }
+}
+
+void launch_pack_results(hipStream_t st, const PackArgs& a, int total_dw, uint32_t* out) {
+    if (total_dw <= 0) return;
+    hipLaunchKernelGGL(k_pack_results, dim3(cdiv(total_dw, 256)), dim3(256), 0, st, a, out);
+}
+
 void launch_triangulate(hipStream_t st, const double* P, const float2* p0, const float2* p1, int n, double* pts3) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_triangulate, dim3(cdiv(n, 256)), dim3(256), 0, st, P, p0, p1, n, pts3);

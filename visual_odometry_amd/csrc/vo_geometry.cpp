@@ -117,6 +117,22 @@ int geom_prepare(vo_ctx* c, int npairs, int n_cap, uint64_t seed, int H) {
 
 // Essential matrix for npairs point sets resident on the device (points of pair p at
 // d_p0 + p*n_cap).  Leaves EstState[p] (E, status, n_inliers) and d_mask on the device.
+// The camera table (the same K for every pair) stays on the device between calls; it is sent again only
+// when K changes or more pairs are needed.  The caller has sized d_cam.
+static int geom_upload_cam(vo_ctx* c, int npairs, const double* K) {
+    const double k4[4] = {K[0], K[4], K[2], K[5]};
+    if (c->d_cam.p == c->cam_ptr && npairs <= c->cam_pairs && memcmp(k4, c->cam_cache, sizeof(k4)) == 0)
+        return VO_OK;  // (a regrown d_cam is a new allocation: its pointer differs)
+    VO_TRY(vo_ensure_pinned(c, c->h_misc, std::max((size_t)npairs * sizeof(CamK), (size_t)4096)));
+    CamK* hk = c->h_misc.as<CamK>();
+    for (int p = 0; p < npairs; p++) hk[p] = {K[0], K[4], K[2], K[5]};
+    VO_HIP(c, hipMemcpyAsync(c->d_cam.p, hk, (size_t)npairs * sizeof(CamK), hipMemcpyHostToDevice, c->stream));
+    memcpy(c->cam_cache, k4, sizeof(k4));
+    c->cam_pairs = npairs;
+    c->cam_ptr = c->d_cam.p;
+    return VO_OK;
+}
+
 int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0, const float2* d_p1,
                             const int* d_n, int n_host, const double* K, int method, double prob,
                             double threshold, int max_iters) {
@@ -128,10 +144,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
     int niters = H;
     if (method == VO_LMEDS) niters = std::min(H, std::max(ransac_update_num_iters(prob, 0.45, 5, H), 3));
     // camera (same K for every pair)
-    VO_TRY(vo_ensure_pinned(c, c->h_misc, std::max((size_t)npairs * sizeof(CamK), (size_t)4096)));
-    CamK* hk = c->h_misc.as<CamK>();
-    for (int p = 0; p < npairs; p++) hk[p] = {K[0], K[4], K[2], K[5]};
-    VO_HIP(c, hipMemcpyAsync(c->d_cam.p, hk, (size_t)npairs * sizeof(CamK), hipMemcpyHostToDevice, st));
+    VO_TRY(geom_upload_cam(c, npairs, K));
 
     EstState* S = c->d_state.as<EstState>();
     double2* x1 = c->d_x1.as<double2>();
@@ -187,10 +200,7 @@ int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, s
     VO_TRY(vo_ensure(c, c->d_pts4, np * 4 * n_cap * sizeof(double)));
     const int n_grid = d_n ? n_cap : n_host;
     if (d_p0) {
-        VO_TRY(vo_ensure_pinned(c, c->h_misc, std::max(np * sizeof(CamK), (size_t)4096)));
-        CamK* hk = c->h_misc.as<CamK>();
-        for (int p = 0; p < npairs; p++) hk[p] = {K[0], K[4], K[2], K[5]};
-        VO_HIP(c, hipMemcpyAsync(c->d_cam.p, hk, np * sizeof(CamK), hipMemcpyHostToDevice, st));
+        VO_TRY(geom_upload_cam(c, npairs, K));
         launch_normalize(st, d_p0, d_p1, c->d_cam.as<CamK>(), nullptr, d_n, n_host, n_cap, n_grid,
                          c->d_x1.as<double2>(), c->d_x2.as<double2>(), npairs);
     }

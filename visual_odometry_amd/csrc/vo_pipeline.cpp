@@ -40,16 +40,35 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
     VO_TRY(vo_ensure_pinned(c, c->h_state, (size_t)npairs * sizeof(EstState)));
     VO_TRY(vo_ensure_pinned(c, c->h_pose, (size_t)npairs * sizeof(PoseState)));
     VO_TRY(vo_ensure_pinned(c, c->h_good, (size_t)npairs * sizeof(int)));
-    VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, (size_t)npairs * sizeof(EstState), hipMemcpyDeviceToHost,
-                             c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, (size_t)npairs * sizeof(PoseState), hipMemcpyDeviceToHost,
-                             c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_good.p, c->d_ngood.p, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost,
-                             c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_nkp.p, c->d_nkp.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
-                             c->stream));
+    // One copy instead of five: the result tables (estimator and pose states, match counts, keypoint
+    // counts, selection flags) are gathered into one device buffer and cross the bus together.
+    PackArgs pa;
+    const void* src[5] = {c->d_state.p, c->d_pose.p, c->d_ngood.p, c->d_nkp.p, c->d_flags.p};
+    const size_t bytes[5] = {(size_t)npairs * sizeof(EstState), (size_t)npairs * sizeof(PoseState),
+                             (size_t)npairs * sizeof(int), (size_t)n_frames * sizeof(int),
+                             (size_t)n_frames * sizeof(int)};
+    int at = 0;
+    for (int i = 0; i < 5; i++) {
+        pa.src[i] = static_cast<const uint32_t*>(src[i]);
+        pa.ndw[i] = (int)(bytes[i] / 4);
+        pa.at[i] = at;
+        c->pack_at[i] = (size_t)at * 4;
+        c->pack_bytes[i] = bytes[i];
+        at += (pa.ndw[i] + 3) & ~3;
+    }
+    VO_TRY(vo_ensure(c, c->d_pack, (size_t)at * 4));
+    VO_TRY(vo_ensure_pinned(c, c->h_pack, (size_t)at * 4));
+    launch_pack_results(c->stream, pa, at, c->d_pack.as<uint32_t>());
+    VO_TRY(vo_check_launch(c, "result gather"));
+    VO_HIP(c, hipMemcpyAsync(c->h_pack.p, c->d_pack.p, (size_t)at * 4, hipMemcpyDeviceToHost, c->stream));
     c->pipe_ncap = n_cap;
     return VO_OK;
+}
+
+// after the synchronisation: the gathered tables back into the pinned buffers the rest of the code reads
+static void pairs_unpack(vo_ctx* c) {
+    void* dst[5] = {c->h_state.p, c->h_pose.p, c->h_good.p, c->h_nkp.p, c->h_flags.p};
+    for (int i = 0; i < 5; i++) memcpy(dst[i], c->h_pack.as<char>() + c->pack_at[i], c->pack_bytes[i]);
 }
 
 // Queue the whole batch on the context's stream without a host round trip: ORB with the
@@ -75,8 +94,6 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
         VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
     }
     VO_TRY(pairs_after_selection(c, n_frames, n_bound, K, prm));
-    VO_HIP(c, hipMemcpyAsync(c->h_flags.p, c->d_flags.p, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost,
-                             c->stream));
     memcpy(c->pend_K, K, sizeof(c->pend_K));
     c->pend_prm = *prm;
     c->pend_frames = n_frames;
@@ -91,6 +108,7 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results) {
     c->pend_frames = 0;
     const int npairs = n_frames - 1;
     VO_HIP(c, hipStreamSynchronize(c->stream));
+    pairs_unpack(c);
     int flagged = 0;
     for (int f = 0; f < n_frames; f++) flagged |= c->h_flags.as<int>()[f];
     c->last_flags = flagged;
@@ -101,6 +119,7 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results) {
         if (max_n > 0) VO_TRY(feat_describe(c, n_frames, max_n, true, true));
         VO_TRY(pairs_after_selection(c, n_frames, max_n, c->pend_K, &c->pend_prm));
         VO_HIP(c, hipStreamSynchronize(c->stream));
+        pairs_unpack(c);
     }
     c->pipe_nkp.assign(c->h_nkp.as<int>(), c->h_nkp.as<int>() + n_frames);
 
