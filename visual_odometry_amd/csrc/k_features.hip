@@ -438,8 +438,12 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g,
                                                    const unsigned long long* __restrict__ masks,
-                                                   int* __restrict__ segbase, int* __restrict__ lvlofs) {
+                                                   int* __restrict__ segbase, int* __restrict__ lvlofs,
+                                                   int* __restrict__ flags) {
     __shared__ int wtot[16];
+    // the per-frame selection flags start at zero (this kernel runs once per batch before the selection)
+    if (threadIdx.x == 0) flags[blockIdx.x] = 0;
+    if (threadIdx.x == 1 && blockIdx.x == 0) flags[gridDim.x] = 0;
     __shared__ int s_total;
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = g->segs_total, nlevels = g->nlevels;
@@ -1280,8 +1284,8 @@ void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, c
 }
 
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
-                     int* lvlofs, int nframes) {
-    hipLaunchKernelGGL(k_row_scan, dim3(nframes), dim3(1024), 0, st, d_geom, masks, segbase, lvlofs);
+                     int* lvlofs, int* flags, int nframes) {
+    hipLaunchKernelGGL(k_row_scan, dim3(nframes), dim3(1024), 0, st, d_geom, masks, segbase, lvlofs, flags);
 }
 
 void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,

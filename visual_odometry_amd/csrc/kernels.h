@@ -107,7 +107,7 @@ void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
                      unsigned long long* masks, int threshold, int border, int nms, int nframes);
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
-                     int* lvlofs, int nframes);
+                     int* lvlofs, int* flags, int nframes);
 void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
                        const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes);
 void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,

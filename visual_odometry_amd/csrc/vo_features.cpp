@@ -261,7 +261,7 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
                         std::min(std::max(fast_threshold, 0), 255), border, nms, nframes);
     }
     launch_row_scan(st, dg, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(), c->d_lvlofs.as<int>(),
-                    nframes);
+                    c->d_flags.as<int>(), nframes);
     launch_cand_write(st, dg, g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
                       c->d_score.as<uint8_t>(), nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
     c->cand_nms = nms;
@@ -315,7 +315,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     hipStream_t st = c->stream;
     Quotas q;
     for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) q.q[l] = l < c->geom.nlevels ? c->quota[l] : 0;
-    VO_HIP(c, hipMemsetAsync(c->d_flags.p, 0, (size_t)(nframes + 1) * sizeof(int), st));
+    // d_flags was zeroed by the row scan of this batch (feat_detect)
     launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom, c->d_lvlofs.as<int>(),
                       c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                       c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes);
