@@ -390,7 +390,7 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
-                        c->d_cand.as<Cand>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
+                        c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                         c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                         nframes);
     launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
