@@ -233,6 +233,21 @@ def main():
     roofline["valu"] = {"achieved_Tpairs_s": desc_pairs / knn_avg_s / 1e12, "ceiling_Tpairs_s": 2.7,
                         "frac": desc_pairs / knn_avg_s / 2.7e12}
 
+    # ---- the same steps with the frames in pinned host memory: every chunk crosses PCIe inside the timed
+    # region (the copy of one chunk overlaps the kernels of the others).  Reported beside `value`, never as it.
+    pcie = None
+    if rank == 0 and world == 1:
+        pinned = torch.from_numpy(frames).pin_memory()
+        seq.run(pinned.data_ptr(), n, w, h, w, w * h, K, params, mem=api.MEM_HOST_PINNED)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            seq.run(pinned.data_ptr(), n, w, h, w, w * h, K, params, mem=api.MEM_HOST_PINNED)
+        tp = time.perf_counter() - tp
+        pcie = {"value": args.steps * pairs_per_step / tp, "unit": "frame-pairs/s",
+                "note": "frames in pinned host memory, uploads inside the timed region"}
+        del pinned
+
     # ---- 8k x 8k matcher (BASELINE config 3 shape), same accounting -----------------------------
     matcher_8k = None
     if rank == 0 and not args.no_8k:
@@ -282,6 +297,7 @@ def main():
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
             "detector_roofline": detector,
+            "pcie_inclusive": pcie,
             "stage_us_per_step": {"fast_score_kernel": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
                                   "knn2_partial_kernel": knn_avg_s * 1e6,
                                   "solve5_kernels_per_step": solve_ms / 5 * 1e3},
