@@ -160,6 +160,17 @@ struct vo_seq {
     int chunk_pairs = 32;
     std::vector<vo_ctx*> ctx;
     std::vector<PinnedBuf> stage;  // per context: pinned staging of one chunk (pageable input)
+    // Pinned, tightly packed host frames: a context owns two device image buffers and a copy stream, so
+    // the upload of its next chunk runs while the current chunk computes instead of ahead of it on the
+    // same stream.
+    struct Prefetch {
+        void* img[2] = {nullptr, nullptr};
+        size_t cap = 0;
+        hipStream_t copy = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        int chunk[2] = {-1, -1};  // chunk whose frames buffer b holds (or is receiving)
+    };
+    std::vector<Prefetch> pre;
     double submit_ms = 0, wait_ms = 0;  // host time of the last vo_seq_run spent queueing / waiting
     int chunks = 0;
     char err[512];
@@ -199,6 +210,7 @@ int vo_seq_create(int device, const vo_limits* limits, int n_streams, int pairs_
     s->chunk_pairs = pairs_per_chunk;
     s->err[0] = 0;
     s->stage.resize(n_streams);
+    s->pre.resize(n_streams);
     for (int i = 0; i < n_streams; i++) {
         vo_ctx* c = nullptr;
         const int rc = vo_ctx_create(device, &lim, &c);
@@ -218,6 +230,15 @@ void vo_seq_destroy(vo_seq* s) {
         (void)hipSetDevice(s->device);
         (void)hipStreamSynchronize(s->ctx[i]->stream);
         if (s->stage[i].p) (void)hipHostFree(s->stage[i].p);
+        vo_seq::Prefetch& P = s->pre[i];
+        if (P.copy) {
+            (void)hipStreamSynchronize(P.copy);
+            (void)hipStreamDestroy(P.copy);
+        }
+        for (int b = 0; b < 2; b++) {
+            if (P.ev[b]) (void)hipEventDestroy(P.ev[b]);
+            if (P.img[b]) (void)hipFree(P.img[b]);
+        }
         vo_ctx_destroy(s->ctx[i]);
     }
     delete s;
@@ -247,6 +268,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
     const int S = (int)s->ctx.size(), B = s->chunk_pairs;
     const int npairs = n_frames - 1;
     const int nchunks = (npairs + B - 1) / B;
+    auto first_of = [&](int chunk) { return std::min(chunk * B, npairs); };  // first pair (= first frame) of a chunk
     const size_t img = (size_t)w * h;
     int rc = VO_OK;
     int collected = 0;  // chunks [0, collected) have their results
@@ -254,6 +276,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     s->submit_ms = s->wait_ms = 0;
     s->chunks = nchunks;
+    for (auto& P : s->pre) P.chunk[0] = P.chunk[1] = -1;  // nothing of this run is on the device yet
     auto collect = [&](int k) {
         const auto t0 = clk::now();
         const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], results + (size_t)k * B));
@@ -280,6 +303,45 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
             rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm));
             continue;
         }
+        if (mem == VO_MEM_HOST_PINNED && stride == w && frame_stride == img) {
+            vo_seq::Prefetch& P = s->pre[slot];
+            const size_t need = (size_t)(B + 1) * img;
+            hipError_t pe = hipSuccess;
+            if (!P.copy) pe = hipStreamCreateWithFlags(&P.copy, hipStreamNonBlocking);
+            for (int b = 0; b < 2 && pe == hipSuccess; b++)
+                if (!P.ev[b]) pe = hipEventCreateWithFlags(&P.ev[b], hipEventDisableTiming);
+            if (pe == hipSuccess && P.cap < need) {
+                (void)hipStreamSynchronize(P.copy);
+                (void)hipStreamSynchronize(c->stream);
+                for (int b = 0; b < 2 && pe == hipSuccess; b++) {
+                    if (P.img[b]) (void)hipFree(P.img[b]);
+                    P.img[b] = nullptr;
+                    P.chunk[b] = -1;
+                    pe = hipMalloc(&P.img[b], need);
+                }
+                P.cap = pe == hipSuccess ? need : 0;
+            }
+            auto upload = [&](int chunk, int b) {
+                const int g0 = first_of(chunk), gn = first_of(chunk + 1) - g0 + 1;
+                hipError_t e2 = hipMemcpyAsync(P.img[b], frames + (size_t)g0 * frame_stride, (size_t)gn * img,
+                                               hipMemcpyHostToDevice, P.copy);
+                if (e2 == hipSuccess) e2 = hipEventRecord(P.ev[b], P.copy);
+                P.chunk[b] = chunk;
+                return e2;
+            };
+            const int b = (k / S) & 1;
+            if (pe == hipSuccess && P.chunk[b] != k) pe = upload(k, b);  // first chunks of a run: nothing prefetched
+            if (pe == hipSuccess) pe = hipStreamWaitEvent(c->stream, P.ev[b], 0);
+            if (pe != hipSuccess) {
+                rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(pe));
+                break;
+            }
+            rc = s->from(c, pairs_submit(c, static_cast<const uint8_t*>(P.img[b]), nf, w, h, w, img, K, prm));
+            // the other buffer held chunk k - S, which has been collected: send chunk k + S into it now
+            if (rc == VO_OK && k + S < nchunks && upload(k + S, b ^ 1) != hipSuccess)
+                rc = s->fail(VO_ERR_DEVICE, "frame prefetch failed");
+            continue;
+        }
         // host frames: tightly packed copy of the chunk into the context's image buffer
         if ((rc = s->from(c, vo_ensure(c, c->d_img, (size_t)(B + 1) * img))) != VO_OK) break;
         hipError_t e = hipSuccess;
@@ -304,6 +366,9 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
         }
         rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm));
     }
+    if (rc != VO_OK)
+        for (auto& P : s->pre)
+            if (P.copy) (void)hipStreamSynchronize(P.copy);  // a prefetch nobody will wait for
     // drain in order (also after an error, so that no context is left with work in flight)
     for (int k = collected; k < nchunks; k++) {
         vo_ctx* c = s->ctx[k % S];
