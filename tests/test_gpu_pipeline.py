@@ -116,6 +116,29 @@ def test_pairs_run_frames_with_more_corners_than_the_candidate_list():
         ctx.close()
 
 
+def test_pairs_run_with_one_frame_on_the_host_selection_path(vo, frames):
+    """Only the middle frame overflows the device selection (a corner-dense noise frame): it alone goes
+    through the host selection, its neighbours keep their device picks, and the batch equals the
+    single-image calls frame by frame."""
+    fr, _, _ = frames
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (376, 1241)).astype(np.float32)
+    k = np.ones(3, np.float32) / 3
+    noise = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, noise)
+    noise = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, noise)
+    batch = np.ascontiguousarray(np.stack([fr[0], noise.astype(np.uint8), fr[1]]))
+    d = torch.from_numpy(batch).to("cuda:0")
+    torch.cuda.synchronize()
+    res = vo.pairs_run_dev(d.data_ptr(), 3, 1241, 376, 1241, 1241 * 376, K, api.pair_params(1000))
+    assert vo.get_option(api.OPT_LAST_FLAGS) & 1
+    got = [vo.pairs_get_frame(f) for f in range(3)]
+    for f in range(3):
+        sk, sd = vo.orb_detect_compute(batch[f], api.orb_params(1000))
+        assert len(sk) > 900
+        assert np.array_equal(got[f][0], sk) and np.array_equal(got[f][1], sd), f
+    assert res[0].n_kp0 == len(got[0][0]) and res[1].n_kp1 == len(got[2][0])
+
+
 def test_pairs_run_flat_frames(vo):
     """No keypoints anywhere: every pair reports status VO_ERR_FAILED and zero counts."""
     fr = np.full((3, 376, 1241), 77, np.uint8)

@@ -185,7 +185,7 @@ int vo_xfer_finish(vo_ctx* c);                                           // sync
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);
 int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes, int fast_threshold,
                 int border, int nms);
-int feat_fetch_cands(vo_ctx* c, int nframes);
+int feat_fetch_cands(vo_ctx* c, int nframes, const char* only = nullptr);  // only[f] != 0: fetch frame f
 int feat_select_dev(vo_ctx* c, int nframes, int n_bound);
 int feat_select_host(vo_ctx* c, int nframes, int* max_n_out);
 int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_selection);

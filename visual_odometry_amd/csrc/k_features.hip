@@ -977,8 +977,8 @@ __device__ __forceinline__ int row16_sum(int v) {
 // offsets of the frame arrive together (uniform addresses), the level's geometry is fetched while the
 // keypoint copy is in flight, the row and mask loads go out together.
 __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
-                                                  const Cand* __restrict__ sel, int max_cand,
-                                                  const Cand* __restrict__ selcand,
+                                                  const Cand* __restrict__ sel, const int* __restrict__ flags,
+                                                  int max_cand, const Cand* __restrict__ selcand,
                                                   const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
@@ -1002,7 +1002,8 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
     const int r = min((int)threadIdx.x & 31, 30);
     Cand cd;
     int lg;
-    if (sel) {
+    // sel != NULL: the frames flagged in `flags` take their keypoints from the host selection
+    if (sel && flags[f] != 0) {
         cd = sel[(size_t)f * kp_cap + k];
         lg = cd.level;
     } else {
@@ -1309,12 +1310,12 @@ void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom
                        n_bound, nframes);
 }
 
-void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel,
+void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
                      int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes) {
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, 8), nframes);
-    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, max_cand, selcand, selcnt, lvlofs,
+    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, flags, max_cand, selcand, selcnt, lvlofs,
                        nkp, kp_cap, out);
 }
 

@@ -271,7 +271,8 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
 // Level offsets to the host; when a frame has more FAST corners than the candidate lists hold (cv has no
 // such limit) the lists grow and are written again from the mask table, segment bases and score map,
 // which are complete.  Synchronises.
-static int feat_cand_capacity(vo_ctx* c, int nframes) {
+static int feat_cand_capacity(vo_ctx* c, int nframes, bool* grew = nullptr) {
+    if (grew) *grew = false;
     const PyrGeom& g = c->geom;
     hipStream_t st = c->stream;
     const size_t lv_bytes = (size_t)nframes * (VO_ORB_MAX_LEVELS + 1) * sizeof(int);
@@ -281,6 +282,7 @@ static int feat_cand_capacity(vo_ctx* c, int nframes) {
     int most = 0;
     for (int f = 0; f < nframes; f++) most = std::max(most, lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels]);
     if (most <= c->max_cand) return VO_OK;
+    if (grew) *grew = true;  // the regrown selection buffer lost the device picks of every frame
     const size_t nf = (size_t)c->feat_frames;
     c->max_cand = (most + 65535) & ~65535;
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
@@ -291,7 +293,7 @@ static int feat_cand_capacity(vo_ctx* c, int nframes) {
 }
 
 // Candidate lists to the host (plain FAST output, host selection path).  Synchronises.
-int feat_fetch_cands(vo_ctx* c, int nframes) {
+int feat_fetch_cands(vo_ctx* c, int nframes, const char* only) {
     const PyrGeom& g = c->geom;
     hipStream_t st = c->stream;
     VO_TRY(feat_cand_capacity(c, nframes));
@@ -299,7 +301,7 @@ int feat_fetch_cands(vo_ctx* c, int nframes) {
     const int* lv = c->h_lvlofs.as<int>();
     for (int f = 0; f < nframes; f++) {
         const int total = lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels];
-        if (total > 0)
+        if (total > 0 && (!only || only[f]))
             VO_HIP(c, hipMemcpyAsync(c->h_cand.as<Cand>() + (size_t)f * c->max_cand,
                                      c->d_cand.as<Cand>() + (size_t)f * c->max_cand, (size_t)total * sizeof(Cand),
                                      hipMemcpyDeviceToHost, st));
@@ -322,16 +324,22 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     return vo_check_launch(c, "keypoint selection");
 }
 
-// The same selection on the host with libstdc++ itself (exact for every input; used when the
-// device selection raised a flag).  Harris for every candidate, candidates to the host, selection
-// on host threads, upload of the selected keypoints.  Synchronises.
+// The same selection on the host with libstdc++ itself (exact for every input), for the frames whose
+// device selection raised a flag (h_flags, h_nkp hold the device's flags and counts of the batch): Harris
+// for every candidate, the flagged frames' candidates to the host, selection on host threads, upload of
+// their keypoints.  The other frames keep their device picks; d_flags afterwards marks the frames whose
+// keypoints come from d_sel.  Synchronises.
 int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     const PyrGeom& g = c->geom;
-    VO_TRY(feat_cand_capacity(c, nframes));  // before Harris: a regrown list starts without responses
+    bool grew = false;
+    VO_TRY(feat_cand_capacity(c, nframes, &grew));  // before Harris: a regrown list starts without responses
+    std::vector<char> redo(nframes);
+    int* hflags = c->h_flags.as<int>();
+    for (int f = 0; f < nframes; f++) redo[f] = grew || hflags[f] != 0;
     launch_harris(c->stream, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->d_lvlofs.as<int>(),
                   c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
     VO_TRY(vo_check_launch(c, "harris"));
-    VO_TRY(feat_fetch_cands(c, nframes));
+    VO_TRY(feat_fetch_cands(c, nframes, redo.data()));
     VO_TRY(vo_ensure_pinned(c, c->h_sel, (size_t)nframes * c->kp_cap * sizeof(Cand)));
     const int* lv = c->h_lvlofs.as<int>();
     int* nkp = c->h_nkp.as<int>();
@@ -352,25 +360,28 @@ int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
         }
         return n;
     };
-    const int nthreads = std::max(1, std::min({nframes, 16, (int)std::thread::hardware_concurrency()}));
+    std::vector<int> todo;
+    for (int f = 0; f < nframes; f++)
+        if (redo[f]) todo.push_back(f);
+    const int nthreads = std::max(1, std::min({(int)todo.size(), 16, (int)std::thread::hardware_concurrency()}));
     if (nthreads == 1) {
         std::vector<RespIdx> v;
-        for (int f = 0; f < nframes; f++) nkp[f] = select_frame(f, v);
+        for (int f : todo) nkp[f] = select_frame(f, v);
     } else {
         std::vector<std::thread> pool;
         for (int t = 0; t < nthreads; t++)
             pool.emplace_back([&, t]() {
                 std::vector<RespIdx> v;
-                for (int f = t; f < nframes; f += nthreads) nkp[f] = select_frame(f, v);
+                for (size_t i = t; i < todo.size(); i += nthreads) nkp[todo[i]] = select_frame(todo[i], v);
             });
         for (auto& th : pool) th.join();
     }
     int max_n = 0;
     for (int f = 0; f < nframes; f++) {
-        const int n = nkp[f];
+        const int n = nkp[f];  // frames not redone: the device's count
         if (n < 0) return c->fail(VO_ERR_CAPACITY, "frame %d selects more than %d keypoints", f, c->kp_cap);
         max_n = std::max(max_n, n);
-        if (n > 0)
+        if (n > 0 && redo[f])
             VO_HIP(c, hipMemcpyAsync(c->d_sel.as<Cand>() + (size_t)f * c->kp_cap,
                                      c->h_sel.as<Cand>() + (size_t)f * c->kp_cap, (size_t)n * sizeof(Cand),
                                      hipMemcpyHostToDevice, c->stream));
@@ -378,6 +389,8 @@ int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     nkp[nframes] = 0;
     VO_HIP(c, hipMemcpyAsync(c->d_nkp.p, nkp, (size_t)(nframes + 1) * sizeof(int), hipMemcpyHostToDevice,
                              c->stream));
+    for (int f = 0; f < nframes; f++) hflags[f] = redo[f] ? (hflags[f] ? hflags[f] : VO_SEL_OVERSIZE) : 0;
+    VO_HIP(c, hipMemcpyAsync(c->d_flags.p, hflags, (size_t)nframes * sizeof(int), hipMemcpyHostToDevice, c->stream));
     *max_n_out = max_n;
     return VO_OK;
 }
@@ -390,7 +403,7 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
-                        c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
+                        c->d_flags.as<int>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                         c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                         nframes);
     launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
