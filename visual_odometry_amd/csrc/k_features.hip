@@ -639,8 +639,9 @@ __device__ __forceinline__ float harris_response(const uint8_t* img, int pitch, 
 // Harris response of every candidate: only the host selection path needs all of them.
 __global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                 const int* __restrict__ lvlofs, Cand* __restrict__ cand,
-                                                int max_cand) {
+                                                int max_cand, const int* __restrict__ only_flagged) {
     const int f = blockIdx.y;
+    if (only_flagged && only_flagged[f] == 0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int total = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + g->nlevels], max_cand);
     if (i >= total) return;
@@ -1293,9 +1294,9 @@ void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
 }
 
 void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
-                   int max_cand, int grid_cand, int nframes) {
+                   int max_cand, int grid_cand, const int* only_flagged, int nframes) {
     dim3 grid(cdiv(grid_cand, 256), nframes);
-    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, st, pyr, d_geom, lvlofs, cand, max_cand);
+    hipLaunchKernelGGL(k_harris, grid, dim3(256), 0, st, pyr, d_geom, lvlofs, cand, max_cand, only_flagged);
 }
 
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,

@@ -111,7 +111,7 @@ void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long 
 void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
                        const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes);
 void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
-                   int max_cand, int grid_cand, int nframes);
+                   int max_cand, int grid_cand, const int* only_flagged, int nframes);
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
                        const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
                        int* selcnt, int* flags, int* nkp, int n_bound, int nframes);

@@ -336,8 +336,9 @@ int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     std::vector<char> redo(nframes);
     int* hflags = c->h_flags.as<int>();
     for (int f = 0; f < nframes; f++) redo[f] = grew || hflags[f] != 0;
+    // only for the flagged frames (d_flags still holds the device's flags; after a regrowth every frame)
     launch_harris(c->stream, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->d_lvlofs.as<int>(),
-                  c->d_cand.as<Cand>(), c->max_cand, c->max_cand, nframes);
+                  c->d_cand.as<Cand>(), c->max_cand, c->max_cand, grew ? nullptr : c->d_flags.as<int>(), nframes);
     VO_TRY(vo_check_launch(c, "harris"));
     VO_TRY(feat_fetch_cands(c, nframes, redo.data()));
     VO_TRY(vo_ensure_pinned(c, c->h_sel, (size_t)nframes * c->kp_cap * sizeof(Cand)));
@@ -406,7 +407,9 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
                         c->d_flags.as<int>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                         c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                         nframes);
-    launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
+    // host_selection = the redo of a batch whose first pass already blurred the pyramid
+    if (!host_selection)
+        launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
     launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
                   c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
     return vo_check_launch(c, "feature description");
