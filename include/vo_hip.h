@@ -95,6 +95,20 @@ int vo_match_filter(vo_ctx* ctx, const vo_dmatch* knn, const int* n_valid, int n
                     const vo_keypoint* kq, const vo_keypoint* kt, float ratio, float max_disp,
                     vo_dmatch* good, int* n_good);
 
+/* Cross-check option (BASELINE.json north_star: "ratio and cross-check filtering").  The reference's
+ * matcher is BFMatcher(NORM_HAMMING, crossCheck=false) (src/matcher/matcher.cpp:10), so this is off by
+ * default everywhere; cv's own crossCheck mode only exists for k = 1 and cannot be combined with the
+ * k = 2 ratio test the reference uses, hence the rule here is stated, not inherited: a match
+ * (q -> t) that passed the ratio and displacement tests is kept only if q is also the nearest query
+ * of train row t (Hamming distance, ties to the lower query index: cv's rule in the other direction).
+ * vo_knn2_hamming_cross runs both directions in ONE launch and returns rev_nn[t] = nearest query of
+ * train row t (-1 if nq == 0); vo_match_filter_cross applies the rule. */
+int vo_knn2_hamming_cross(vo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes,
+                          vo_dmatch* out, int* n_valid, int* rev_nn);
+int vo_match_filter_cross(vo_ctx* ctx, const vo_dmatch* knn, const int* n_valid, int nq, const int* rev_nn,
+                          int nt, const vo_keypoint* kq, const vo_keypoint* kt, float ratio, float max_disp,
+                          vo_dmatch* good, int* n_good);
+
 /* ---- sfm: replaces the cv calls in updatePose() and matcher() ---------------------------- */
 
 /* cv::findEssentialMat(p0, p1, K, method, prob, threshold, mask)
@@ -139,7 +153,7 @@ typedef struct vo_pair_params {
     double dist_thresh;  /* 200 */
     uint64_t seed;       /* (uint64)-1 */
     int32_t max_iters;   /* 1000 */
-    int32_t reserved;
+    int32_t cross_check; /* 0 (the reference: BFMatcher crossCheck=false, src/matcher/matcher.cpp:10); 1: see vo_match_filter_cross */
 } vo_pair_params;
 
 typedef struct vo_pair_result {

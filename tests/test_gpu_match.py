@@ -122,3 +122,54 @@ def test_match_filter_ratio_boundary(vo, oracle):
     kt = np.zeros(3, oracle.KP_DTYPE)
     nv = np.full(3, 2, np.int32)
     assert np.array_equal(vo.match_filter(knn, nv, kq, kt), oracle.match_filter(knn, nv, kq, kt))
+
+
+def test_knn2_complementary_64_byte_rows(vo, oracle):
+    # distance 512 = 2^9 needs the tenth key bit: q = ~t at 64 bytes must come out LAST, not first
+    rng = np.random.default_rng(11)
+    t = rng.integers(0, 256, (70, 64), dtype=np.uint8)
+    q = t[:40].copy()
+    q[::2] = ~q[::2]
+    g, _ = vo.knn2_hamming(q, t)
+    o, _ = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+    assert (g["distance"][1::2, 0] == 0).all() and (g["distance"][::2, 0] > 0).all()
+    t2 = np.stack([t[0], ~t[0]])
+    g2, _ = vo.knn2_hamming(t[:1], t2)
+    assert list(g2["distance"][0]) == [0.0, 512.0] and list(g2["trainIdx"][0]) == [0, 1]
+
+
+def _rev_nn_numpy(q, t):
+    """Nearest query of every train row: Hamming distance, ties to the lower query index."""
+    lut = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    out = np.full(len(t), -1, np.int32)
+    for j in range(len(t)):
+        if len(q):
+            out[j] = int(np.argmin(lut[np.bitwise_xor(q, t[j][None, :])].sum(1)))  # argmin: first minimum
+    return out
+
+
+@pytest.mark.parametrize("nq,nt", [(300, 500), (2000, 1999), (130, 64), (5, 700)])
+def test_cross_check_option(vo, oracle, nq, nt):
+    """north_star's cross-check filter (off in the reference, matcher.cpp:10): rule stated in
+    include/vo_hip.h, restated here in numpy on top of the oracle's 2-NN + ratio/gate filter."""
+    rng = np.random.default_rng(nq + nt)
+    q, t = synth.matcher_descriptors(max(nq, nt), seed_q=nq, seed_t=nt)
+    q, t = q[:nq], t[:nt]
+    t[::7] = t[0]  # duplicates: ties in both directions
+    kq = np.zeros(nq, oracle.KP_DTYPE)
+    kt = np.zeros(nt, oracle.KP_DTYPE)
+    for k in (kq, kt):
+        k["x"] = rng.uniform(0, 300, len(k)).astype(np.float32)
+        k["y"] = rng.uniform(0, 100, len(k)).astype(np.float32)
+    g, gv, rev = vo.knn2_hamming_cross(q, t)
+    o, ov = oracle.knn2_hamming(q, t)
+    _same_knn(g, o)
+    assert np.array_equal(gv, ov)
+    assert np.array_equal(rev, _rev_nn_numpy(q, t))
+    plain = oracle.match_filter(o, ov, kq, kt, 0.9, 200.0)
+    want = plain[rev[plain["trainIdx"]] == plain["queryIdx"]]
+    got = vo.match_filter(g, gv, kq, kt, 0.9, 200.0, rev_nn=rev)
+    assert np.array_equal(got, want)
+    assert 0 < len(want) <= len(plain)
+    assert np.array_equal(vo.match_filter(g, gv, kq, kt, 0.9, 200.0), plain)  # default stays the reference's

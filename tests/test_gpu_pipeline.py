@@ -147,3 +147,63 @@ def test_pairs_run_flat_frames(vo):
     res = vo.pairs_run_dev(d.data_ptr(), 3, 1241, 376, 1241, 1241 * 376, K, api.pair_params(2000))
     for p in range(2):
         assert res[p].n_kp0 == 0 and res[p].n_good == 0 and res[p].status == 4
+
+
+def test_pairs_run_cross_check_option(vo, frames):
+    """cross_check = 1 in vo_pair_params: the batched path keeps exactly the matches the single calls
+    keep with vo_knn2_hamming_cross + vo_match_filter_cross, and a subset of the default's."""
+    fr, _, _ = frames
+    d = torch.from_numpy(fr).to("cuda:0")
+    torch.cuda.synchronize()
+    n, h, w = fr.shape
+    vo.pairs_run_dev(d.data_ptr(), n, w, h, w, w * h, K, api.pair_params(1000))
+    plain, _, _ = vo.pairs_get_matches(0)
+    res = vo.pairs_run_dev(d.data_ptr(), n, w, h, w, w * h, K, api.pair_params(1000, cross_check=1))
+    k0, d0 = vo.pairs_get_frame(0)
+    k1, d1 = vo.pairs_get_frame(1)
+    good_b, m1_b, _ = vo.pairs_get_matches(0)
+    knn, nv, rev = vo.knn2_hamming_cross(d0, d1)
+    good = vo.match_filter(knn, nv, k0, k1, rev_nn=rev)
+    assert np.array_equal(good, good_b) and res[0].n_good == len(good)
+    assert 0 < len(good) < len(plain)
+    assert set(map(tuple, good[["queryIdx", "trainIdx"]].tolist())) <= set(map(tuple, plain[["queryIdx", "trainIdx"]].tolist()))
+    assert res[0].status == 0 and res[0].n_inliers == int(m1_b.sum())
+
+
+def test_pairs_run_stress_config_end_to_end(oracle):
+    """BASELINE configs[2] whole, not by stage: nfeatures 8192, 8 levels, 4096 RANSAC hypotheses through
+    vo_pairs_run_dev against the oracle run stage by stage on the same two frames."""
+    fr, _, _ = synth.make_sequence(21, 2)
+    ctx = api.VoContext(0)
+    try:
+        d = torch.from_numpy(fr).to("cuda:0")
+        torch.cuda.synchronize()
+        n, h, w = fr.shape
+        res = ctx.pairs_run_dev(d.data_ptr(), n, w, h, w, w * h, K, api.pair_params(8192, max_iters=4096))
+        po = oracle.orb_params(8192)
+        k0, d0 = oracle.orb_detect_compute(fr[0], po)
+        k1, d1 = oracle.orb_detect_compute(fr[1], po)
+        assert len(k0) > 7000
+        g0 = ctx.pairs_get_frame(0)
+        g1 = ctx.pairs_get_frame(1)
+        assert np.array_equal(g0[0], k0) and np.array_equal(g0[1], d0)
+        assert np.array_equal(g1[0], k1) and np.array_equal(g1[1], d1)
+        knn, nv = oracle.knn2_hamming(d0, d1)
+        good = oracle.match_filter(knn, nv, k0, k1, 0.7, 200.0)
+        gg, m1, m2 = ctx.pairs_get_matches(0)
+        assert np.array_equal(gg, good)
+        p0 = np.stack([k0["x"][good["queryIdx"]], k0["y"][good["queryIdx"]]], 1)
+        p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
+        rc, E, mask, _ = oracle.find_essential(p0, p1, K, oracle.RANSAC, max_iters=4096)
+        r = res[0]
+        assert rc == r.status == 0
+        Eg = np.array(r.E).reshape(3, 3)
+        # north_star's tolerance (1e-6): the winning sample of this pair is ill-conditioned enough that the two
+        # solvers (QR + Sturm here, Jacobi SVD + Durand-Kerner in the oracle) differ by 1.1e-7 in E
+        assert min(np.abs(Eg - E).max(), np.abs(Eg + E).max()) < 1e-6
+        assert np.array_equal(m1, mask) and r.n_inliers == int(mask.sum())
+        ng, R, t, pm, _ = oracle.recover_pose(E, p0, p1, K, 200.0, mask)
+        assert np.array_equal(m2, pm) and r.n_pose == ng
+        assert np.abs(np.array(r.R).reshape(3, 3) - R).max() < 1e-6 and np.abs(np.array(r.t) - t).max() < 1e-6
+    finally:
+        ctx.close()

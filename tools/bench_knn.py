@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from visual_odometry_amd import api, synth
 
-frames, poses, K = synth.make_sequence(0, 33, workers=8)
+frames, poses, K = synth.make_sequence(0, 49, workers=8)
 import torch
 d = torch.from_numpy(frames).to("cuda:0")
 ctx = api.VoContext(0)
@@ -25,5 +25,8 @@ for _ in range(10):
     ctx.pairs_run_dev(d.data_ptr(), n_, w, h, w, w * h, K, prm)
 n, ms = ctx.prof_get(0)
 us2 = ms / n * 1e3
-print("Q=%s S=%s  8k: %.1f us (%.2f Tpairs/s)   32x2k: %.1f us (%.2f Tpairs/s)" % (
-    os.environ.get("VO_KNN_Q"), os.environ.get("VO_KNN_SPLITS"), us8, 8192 * 8192 / us8 / 1e6, us2, 32 * 4e6 / us2 / 1e6))
+res = ctx.pairs_run_dev(d.data_ptr(), n_, w, h, w, w * h, K, prm)
+nk = [res[0].n_kp0] + [r.n_kp1 for r in res]
+dp = sum(nk[i] * nk[i + 1] for i in range(n_ - 1))
+print("S=%s  8k: %.1f us (%.2f Tpairs/s)   %dx2k: %.1f us (%.2f Tpairs/s)" % (
+    os.environ.get("VO_KNN_SPLITS"), us8, 8192 * 8192 / us8 / 1e6, n_ - 1, us2, dp / us2 / 1e6))

@@ -166,7 +166,19 @@ class VoContext:
         self._check(self.L.vo_knn2_hamming(self.h, _p(q), nq, _p(t), nt, d, _p(out), _p(nv)))
         return out, nv[:nq]
 
-    def match_filter(self, knn, n_valid, kq, kt, ratio=0.7, max_disp=200.0):
+    def knn2_hamming_cross(self, q, t):
+        """knn2_hamming plus rev_nn[j] = nearest query of train row j (one launch, both directions)."""
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        nq, nt = q.shape[0], t.shape[0]
+        d = q.shape[1] if q.ndim == 2 and nq else (t.shape[1] if t.ndim == 2 and nt else 32)
+        out = np.zeros((nq, 2), DM_DTYPE)
+        nv = np.zeros(max(nq, 1), np.int32)
+        rev = np.zeros(max(nt, 1), np.int32)
+        self._check(self.L.vo_knn2_hamming_cross(self.h, _p(q), nq, _p(t), nt, d, _p(out), _p(nv), _p(rev)))
+        return out, nv[:nq], rev[:nt]
+
+    def match_filter(self, knn, n_valid, kq, kt, ratio=0.7, max_disp=200.0, rev_nn=None):
         knn = np.ascontiguousarray(knn, DM_DTYPE)
         nq = knn.shape[0]
         good = np.zeros(max(nq, 1), DM_DTYPE)
@@ -174,8 +186,13 @@ class VoContext:
         kq = np.ascontiguousarray(kq, KP_DTYPE)
         kt = np.ascontiguousarray(kt, KP_DTYPE)
         nv = np.ascontiguousarray(n_valid, np.int32) if n_valid is not None else None
-        self._check(self.L.vo_match_filter(self.h, _p(knn), _p(nv), nq, _p(kq), _p(kt), C.c_float(ratio),
-                                           C.c_float(max_disp), _p(good), C.byref(n)))
+        if rev_nn is not None:
+            rev = np.ascontiguousarray(rev_nn, np.int32)
+            self._check(self.L.vo_match_filter_cross(self.h, _p(knn), _p(nv), nq, _p(rev), len(rev), _p(kq), _p(kt),
+                                                     C.c_float(ratio), C.c_float(max_disp), _p(good), C.byref(n)))
+        else:
+            self._check(self.L.vo_match_filter(self.h, _p(knn), _p(nv), nq, _p(kq), _p(kt), C.c_float(ratio),
+                                               C.c_float(max_disp), _p(good), C.byref(n)))
         return good[: n.value].copy()
 
     # ---- sfm -----------------------------------------------------------------------------

@@ -117,6 +117,7 @@ struct vo_ctx {
     DevBuf d_q, d_t;    // descriptor uploads (host-pointer entry points)
     DevBuf d_part;      // uint2 [pair][split][nq_cap]
     DevBuf d_knn;       // uint2 [pair][nq_cap]
+    DevBuf d_rev;       // uint2 [pair][nq_cap]: nearest queries of the train rows (cross-check only)
     DevBuf d_good;      // GoodMatch [pair][nq_cap]
     DevBuf d_ngood;     // int [pair]
     DevBuf d_p0, d_p1;  // float2 [pair][nq_cap]

@@ -1,150 +1,281 @@
 // k_match.hip — brute-force Hamming 2-NN (BFMatcher(NORM_HAMMING).knnMatch(k=2)) and the
 // reference's ratio / displacement filter, for gfx950.
 //
-// k_knn2_partial: one query per lane held in registers (4 or 8 x u64), the train range of the
-//   block tiled through LDS (every lane reads the same train row -> LDS broadcast reads),
-//   64-bit xor + popcount, running (best, second) kept as packed keys dist << 23 | index so that
-//   min / max on the key is the (distance, lower-index-first) order cv's insertion rule gives.
-// k_knn2_merge: lexicographic merge of the per-split partial top-2 lists.
-// k_match_filter: ratio test + displacement gate + order-preserving compaction (block scan).
+// k_knn2: a block owns 64 queries of one pair for the whole train range (or one split of it); every
+//   lane of every wave holds one of those queries in registers (8 or 16 dwords) and the block's four
+//   waves each scan a quarter of the train rows.  A wave stages its own rows through a wave-private
+//   LDS tile (no block barrier in the scan), every lane reads the same row (LDS broadcast), and the
+//   running (best, second) are packed keys dist << 22 | index, so min / med3 on the key give the
+//   (distance, lower-index-first) order of cv's insertion rule.  The four waves' pairs meet in LDS
+//   once at the end and wave 0 writes the merged result: no partial table in HBM, no merge launch.
+//   With `cross` the same launch also runs the swapped direction (train rows as queries), which
+//   the mutual-consistency option of the filter needs.
+// k_knn2_merge: only for one small problem spread over train splits to fill the chip (single-pair
+//   entry point): lexicographic merge of the per-split keys.
+// k_match_filter: ratio test + displacement gate (+ optional cross-check) + order-preserving compaction.
 // Reference: src/matcher/matcher.cpp:17-38; SURVEY.md A.3.
 #include "kernels.h"
 
-#define KNN_TILE 256  // train descriptors per LDS tile
+#define KNN_IDX_MASK ((1u << VO_KEY_SHIFT) - 1u)
+#define KNN_GROUP 64  // rows whose (distance << 6 | row) keys fit 16 bits: local top-2 by 16-bit min / max
 
-// W32: uint32 words per descriptor (8 or 16); Q: queries per lane.  A block of 256 threads owns
-// 256 * Q queries (query i of a lane is q0 + i * 256 + thread) and scans rows [tbeg, tend) of the
-// train set.  The tile for the next step is fetched into registers while the current one is
-// scanned (two LDS buffers, one barrier per tile).  Per (query, row): W32 xor + W32 bcnt (the
-// popcount instruction accumulates) + key pack + min / max / min.
-template <int W32, int Q>
-__global__ __launch_bounds__(256) void k_knn2_partial(KnnArgs a) {
-    constexpr int V = W32 / 4;                   // uint4 per descriptor
-    constexpr int LD = KNN_TILE * V / 256;       // uint4 per thread per tile
-    __shared__ uint4 tile[2][KNN_TILE * V];
-    const int pair = blockIdx.z;
-    const int nq = a.d_n ? a.d_n[pair] : a.nq;
-    const int nt = a.d_n ? a.d_n[pair + 1] : a.nt;
-    const int q0 = blockIdx.x * (256 * Q);
-    if (q0 >= nq) return;
-    const uint4* Qp = reinterpret_cast<const uint4*>(a.q + pair * a.q_stride);
-    const uint4* T = reinterpret_cast<const uint4*>(a.t + pair * a.t_stride);
-
-    uint32_t qv[Q][W32];
-#pragma unroll
-    for (int i = 0; i < Q; i++) {
-        const int qr = min(q0 + i * 256 + (int)threadIdx.x, nq - 1);
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            const uint4 v = Qp[(size_t)qr * V + k];
-            qv[i][4 * k] = v.x;
-            qv[i][4 * k + 1] = v.y;
-            qv[i][4 * k + 2] = v.z;
-            qv[i][4 * k + 3] = v.w;
-        }
-    }
-    const int chunk = cdiv(nt, a.splits);
-    const int tbeg = blockIdx.y * chunk;
-    const int tend = min(nt, tbeg + chunk);
-    uint32_t k1[Q], k2[Q];
-#pragma unroll
-    for (int i = 0; i < Q; i++) k1[i] = k2[i] = VO_KEY_INVALID;
-
-    uint4 nxt[LD];
-    auto fetch = [&](int base) {
-        const int cnt = min(KNN_TILE, tend - base) * V;
-#pragma unroll
-        for (int r = 0; r < LD; r++) {
-            const int i = r * 256 + threadIdx.x;
-            nxt[r] = i < cnt ? T[(size_t)base * V + i] : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < LD; r++) tile[buf][r * 256 + threadIdx.x] = nxt[r];
-    };
-    int buf = 0;
-    if (tbeg < tend) {
-        fetch(tbeg);
-        stash(0);
-    }
-    __syncthreads();
-    for (int base = tbeg; base < tend; base += KNN_TILE) {
-        const int n = min(KNN_TILE, tend - base);
-        const bool more = base + KNN_TILE < tend;
-        if (more) fetch(base + KNN_TILE);
-        const uint4* tl = tile[buf];
-#pragma unroll 4
-        for (int j = 0; j < n; j++) {
-            uint32_t tr[W32];
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                const uint4 v = tl[j * V + k];
-                tr[4 * k] = v.x;
-                tr[4 * k + 1] = v.y;
-                tr[4 * k + 2] = v.z;
-                tr[4 * k + 3] = v.w;
-            }
-            const uint32_t idx = (uint32_t)(base + j);
-#pragma unroll
-            for (int i = 0; i < Q; i++) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int k = 0; k < W32; k++) d += __builtin_popcount(qv[i][k] ^ tr[k]);
-                const uint32_t key = (d << VO_KEY_SHIFT) | idx;
-                const uint32_t hi = max(key, k1[i]);
-                k1[i] = min(key, k1[i]);
-                k2[i] = min(k2[i], hi);
-            }
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int i = 0; i < Q; i++) {
-        const int qi = q0 + i * 256 + threadIdx.x;
-        if (qi < nq) a.part[((size_t)pair * a.splits + blockIdx.y) * a.nq_cap + qi] = make_uint2(k1[i], k2[i]);
-    }
+// Issue costs measured on gfx950 (tools/micro/valu_table.hip, profiles/r2_valu_table.txt): v_xor / v_and /
+// v_or / v_add_u32 / v_min_u16 / v_max_u16 run a wave64 in ~2.3 cycles, everything else the kernel needs
+// (v_bcnt, v_lshl_or, 32-bit min / max / med3) in ~4.15.  Hence 16-bit keys inside a group of 64 rows.
+static __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// popcount(x) + acc in one instruction.  Written out because the optimizer otherwise rebalances the
+// sum of eight popcounts into a tree (eight v_bcnt with a zero addend plus three v_add3).
+static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+static __device__ __forceinline__ uint32_t bcnt0(uint32_t x) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+static __device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
+// Train rows reach the lanes as SGPR operands: a wave reads its rows with scalar loads (one
+// s_load_dwordx16 = 64 bytes = two 32-byte rows or one 64-byte row), so the scan loop holds no row in
+// VGPRs, issues no LDS or vector-memory instruction, and the xor takes the row word straight from the
+// scalar register file.  Scalar loads return out of order (only lgkmcnt(0) is a safe wait), so the
+// loads are written as asm and waited for explicitly: the tuple loaded during one batch's arithmetic is
+// waited for at the top of the next batch, just before the following tuple is requested.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ void sload16(u32x16& v, const uint32_t* p) {
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(v) : "s"(p));
+}
+static __device__ __forceinline__ void sload8(u32x8& v, const uint32_t* p) {
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(v) : "s"(p));
+}
+static __device__ __forceinline__ void swait(u32x16& a, u32x16& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+
+// W32: uint32 words per descriptor (8 or 16).  grid: x = 64-query tile, y = train split,
+// z = pair (z >= npairs: the reverse direction of pair z - npairs).
+// Per (query, row): W32 xor + W32 bcnt (the popcount instruction accumulates) + key pack + 16-bit max / min / min.
+template <int W32>
+__global__ __launch_bounds__(256) void k_knn2(KnnArgs a) {
+    constexpr int RPT = 16 / W32;  // rows per 16-dword tuple
+    constexpr int U = 2 * RPT;     // rows per batch (two tuples)
+    __shared__ uint2 wres[4][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool rev = (int)blockIdx.z >= a.npairs;
+    const int pair = rev ? blockIdx.z - a.npairs : blockIdx.z;
+    int nq = a.d_n ? a.d_n[pair] : a.nq;
+    int nt = a.d_n ? a.d_n[pair + 1] : a.nt;
+    const uint32_t* qset = a.q + pair * a.q_stride;
+    const uint32_t* tset = a.t + pair * a.t_stride;
+    if (rev) {
+        const int n = nq;
+        nq = nt;
+        nt = n;
+        const uint32_t* s = qset;
+        qset = tset;
+        tset = s;
+    }
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= nq) return;
+
+    uint32_t qv[W32];
+    {
+        const uint4* Qp = reinterpret_cast<const uint4*>(qset);
+        const int qr = min(q0 + lane, nq - 1);
+#pragma unroll
+        for (int k = 0; k < W32 / 4; k++) {
+            const uint4 v = Qp[(size_t)qr * (W32 / 4) + k];
+            qv[4 * k] = v.x;
+            qv[4 * k + 1] = v.y;
+            qv[4 * k + 2] = v.z;
+            qv[4 * k + 3] = v.w;
+        }
+    }
+    // rows of this split, then of this wave
+    const int per_split = cdiv(nt, a.splits);
+    const int sbeg = min(nt, (int)blockIdx.y * per_split), send = min(nt, sbeg + per_split);
+    const int per_wave = cdiv(send - sbeg, 4);
+    const int wbeg = __builtin_amdgcn_readfirstlane(min(send, sbeg + wave * per_wave));
+    const int wend = __builtin_amdgcn_readfirstlane(min(send, wbeg + per_wave));
+
+    uint32_t k1 = VO_KEY_INVALID, k2 = VO_KEY_INVALID;  // global keys: distance << 22 | row
+    uint32_t l1 = 0xffffu, l2 = 0xffffu;                // keys of the current group: distance << 6 | row - gbase
+    // one row whose words are wave-uniform values (SGPRs) against the lane's query
+    auto row = [&](const uint32_t (&w)[W32], int jj) {
+        uint32_t d = bcnt0(qv[0] ^ w[0]);
+#pragma unroll
+        for (int k = 1; k < W32; k++) d = bcnt_acc(qv[k] ^ w[k], d);
+        const uint32_t key = (d << 6) | (uint32_t)jj;
+        const uint32_t hi = max_u16(key, l1);
+        l1 = min_u16(key, l1);
+        l2 = min_u16(hi, l2);
+    };
+    auto tuple_rows = [&](const u32x16& t, int jj) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            uint32_t w[W32];
+#pragma unroll
+            for (int k = 0; k < W32; k++) w[k] = t[r * W32 + k];
+            row(w, jj + r);
+        }
+    };
+    // fold the group's two keys into the global pair and start a new group
+    auto fold = [&](int gbase) {
+        const uint32_t g1 = ((l1 >> 6) << VO_KEY_SHIFT) | (uint32_t)(gbase + (int)(l1 & 63u));
+        const uint32_t g2 = ((l2 >> 6) << VO_KEY_SHIFT) | (uint32_t)(gbase + (int)(l2 & 63u));
+        const uint32_t e1 = l1 == 0xffffu ? VO_KEY_INVALID : g1, e2 = l2 == 0xffffu ? VO_KEY_INVALID : g2;
+        k2 = med3_u32(e1, k1, k2);
+        k1 = min(e1, k1);
+        k2 = med3_u32(e2, k1, k2);
+        k1 = min(e2, k1);
+        l1 = l2 = 0xffffu;
+    };
+
+    const int nb = (wend - wbeg) / U;  // full batches
+    int r = wbeg, gbase = wbeg, jj = 0;
+    if (nb > 0) {
+        u32x16 A, B, C, D;
+        sload16(A, tset + (size_t)r * W32);
+        sload16(B, tset + (size_t)(r + RPT) * W32);
+        // The SIMD's arbiter serves its oldest wave first, so equal waves finish one after the other and the
+        // SIMD ends its launch with one or two waves left, which cannot fill the VALU.  A wave therefore lowers
+        // its own priority as it advances: the waves of a SIMD stay together and finish together.
+        const int pb1 = (nb / 2) & ~1, pb2 = (nb * 3 / 4) & ~1, pb3 = (nb * 9 / 10) & ~1;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+        for (int b = 0; b < nb; b += 2) {
+            if (b == pb1) __builtin_amdgcn_s_setprio(2);
+            if (b == pb2) __builtin_amdgcn_s_setprio(1);
+            if (b == pb3) __builtin_amdgcn_s_setprio(0);
+            // (A, B) requested one batch ago: wait, then request (C, D) for the batch after this one
+            swait(A, B);
+            const int r1 = min(r + U, wend - U);  // the last trip may have no second batch: reload in bounds
+            sload16(C, tset + (size_t)r1 * W32);
+            sload16(D, tset + (size_t)(r1 + RPT) * W32);
+            tuple_rows(A, jj);
+            tuple_rows(B, jj + RPT);
+            jj += U;
+            if (jj == KNN_GROUP) {
+                fold(gbase);
+                gbase += KNN_GROUP;
+                jj = 0;
+            }
+            swait(C, D);
+            const int r2 = min(r + 2 * U, wend - U);
+            sload16(A, tset + (size_t)r2 * W32);
+            sload16(B, tset + (size_t)(r2 + RPT) * W32);
+            if (b + 1 < nb) {
+                tuple_rows(C, jj);
+                tuple_rows(D, jj + RPT);
+                jj += U;
+                if (jj == KNN_GROUP) {
+                    fold(gbase);
+                    gbase += KNN_GROUP;
+                    jj = 0;
+                }
+            }
+            r += 2 * U;
+        }
+        swait(A, B);  // nothing of this wave's may stay in flight into the tail's own loads
+        __builtin_amdgcn_s_setprio(0);
+        r = wbeg + nb * U;
+    }
+    // the last rows (fewer than a batch), one scalar load each
+#pragma unroll 1
+    for (; r < wend; r++) {
+        uint32_t w[W32];
+        if (W32 == 8) {
+            u32x8 t;
+            sload8(t, tset + (size_t)r * W32);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t));
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = t[k];
+        } else {
+            u32x16 t;
+            sload16(t, tset + (size_t)r * W32);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t));
+#pragma unroll
+            for (int k = 0; k < W32; k++) w[k] = t[k];
+        }
+        row(w, jj);
+        if (++jj == KNN_GROUP) {
+            fold(gbase);
+            gbase += KNN_GROUP;
+            jj = 0;
+        }
+    }
+    fold(gbase);
+
+    wres[wave][lane] = make_uint2(k1, k2);
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        const uint2 p = wres[w][lane];
+        k2 = med3_u32(p.x, k1, k2);
+        k1 = min(p.x, k1);
+        k2 = med3_u32(p.y, k1, k2);
+        k1 = min(p.y, k1);
+    }
+    const int qi = q0 + lane;
+    if (qi >= nq) return;
+    const uint2 out = make_uint2(k1, k2);
+    if (a.splits > 1)
+        a.part[((size_t)blockIdx.z * a.splits + blockIdx.y) * a.nq_cap + qi] = out;
+    else if (rev)
+        a.rev[(size_t)pair * a.nq_cap + qi] = out;
+    else
+        a.knn[(size_t)pair * a.nq_cap + qi] = out;
+}
+
+// splits > 1 only: grid y = pair (+ npairs for the reverse direction)
 __global__ __launch_bounds__(256) void k_knn2_merge(KnnArgs a) {
-    const int pair = blockIdx.y;
-    const int nq = a.d_n ? a.d_n[pair] : a.nq;
+    const bool rev = (int)blockIdx.y >= a.npairs;
+    const int pair = rev ? blockIdx.y - a.npairs : blockIdx.y;
+    const int nq = a.d_n ? a.d_n[pair + (rev ? 1 : 0)] : (rev ? a.nt : a.nq);
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     uint32_t k1 = VO_KEY_INVALID, k2 = VO_KEY_INVALID;
     for (int s = 0; s < a.splits; s++) {
-        const uint2 p = a.part[((size_t)pair * a.splits + s) * a.nq_cap + qi];
-        uint32_t lo = min(p.x, k1), hi = max(p.x, k1);
-        k2 = min(k2, hi);
-        k1 = lo;
-        lo = min(p.y, k1);
-        hi = max(p.y, k1);
-        k2 = min(k2, hi);
-        k1 = lo;
+        const uint2 p = a.part[((size_t)blockIdx.y * a.splits + s) * a.nq_cap + qi];
+        k2 = med3_u32(p.x, k1, k2);
+        k1 = min(p.x, k1);
+        k2 = med3_u32(p.y, k1, k2);
+        k1 = min(p.y, k1);
     }
-    a.knn[(size_t)pair * a.nq_cap + qi] = make_uint2(k1, k2);
+    (rev ? a.rev : a.knn)[(size_t)pair * a.nq_cap + qi] = make_uint2(k1, k2);
 }
 
-void launch_knn2_partial(hipStream_t st, const KnnArgs& a) {
-    if (a.nq <= 0 || a.npairs <= 0) return;
-    dim3 grid(cdiv(a.nq, 256 * a.qpl), a.splits, a.npairs);
-#define VO_KNN(W, QQ) hipLaunchKernelGGL((k_knn2_partial<W, QQ>), grid, dim3(256), 0, st, a)
-    if (a.words == 8) {
-        if (a.qpl == 4) VO_KNN(8, 4);
-        else if (a.qpl == 2) VO_KNN(8, 2);
-        else VO_KNN(8, 1);
-    } else {
-        if (a.qpl >= 2) VO_KNN(16, 2);
-        else VO_KNN(16, 1);
-    }
-#undef VO_KNN
+void launch_knn2(hipStream_t st, const KnnArgs& a) {
+    const int nmax = a.cross ? (a.nq > a.nt ? a.nq : a.nt) : a.nq;
+    if (nmax <= 0 || a.npairs <= 0) return;
+    const int dirs = a.cross ? 2 : 1;
+    dim3 grid(cdiv(nmax, 64), a.splits, a.npairs * dirs);
+    if (a.words == 8) hipLaunchKernelGGL(k_knn2<8>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_knn2<16>, grid, dim3(256), 0, st, a);
 }
 
 void launch_knn2_merge(hipStream_t st, const KnnArgs& a) {
-    if (a.nq <= 0 || a.npairs <= 0) return;
-    hipLaunchKernelGGL(k_knn2_merge, dim3(cdiv(a.nq, 256), a.npairs), dim3(256), 0, st, a);
+    const int nmax = a.cross ? (a.nq > a.nt ? a.nq : a.nt) : a.nq;
+    if (nmax <= 0 || a.npairs <= 0 || a.splits <= 1) return;
+    hipLaunchKernelGGL(k_knn2_merge, dim3(cdiv(nmax, 256), a.npairs * (a.cross ? 2 : 1)), dim3(256), 0, st, a);
 }
 
 // One block per pair; queries processed in chunks of 1024 in index order.
@@ -154,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_match_filter(FilterArgs a) {
     const int pair = blockIdx.x;
     const int nq = a.d_n ? a.d_n[pair] : a.nq;
     const uint2* knn = a.knn + (size_t)pair * a.nq_cap;
+    const uint2* rev = a.rev ? a.rev + (size_t)pair * a.nq_cap : nullptr;
     const vo_keypoint* kq = a.kq + pair * a.kp_stride;
     const vo_keypoint* kt = a.kt + pair * a.kp_stride;
     GoodMatch* good = a.good + (size_t)pair * a.nq_cap;
@@ -173,12 +305,15 @@ __global__ __launch_bounds__(1024) void k_match_filter(FilterArgs a) {
             if (k.x != VO_KEY_INVALID && k.y != VO_KEY_INVALID) {
                 const float d0 = (float)(k.x >> VO_KEY_SHIFT), d1 = (float)(k.y >> VO_KEY_SHIFT);
                 if (d0 < a.ratio * d1) {
-                    const int ti = (int)(k.x & ((1u << VO_KEY_SHIFT) - 1u));
+                    const int ti = (int)(k.x & KNN_IDX_MASK);
+                    // cross-check (off in the reference, matcher.cpp:10): the train row's own nearest
+                    // query, under the same tie rule, must be this query
+                    const bool mutual = !rev || (int)(rev[ti].x & KNN_IDX_MASK) == qi;
                     a0 = make_float2(kq[qi].x, kq[qi].y);
                     a1 = make_float2(kt[ti].x, kt[ti].y);
                     const float dx = a0.x - a1.x, dy = a0.y - a1.y;
                     const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
-                    if (nrm < (double)a.max_disp) {
+                    if (mutual && nrm < (double)a.max_disp) {
                         keep = true;
                         gm.q = qi;
                         gm.t = ti;

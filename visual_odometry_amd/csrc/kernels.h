@@ -153,9 +153,11 @@ void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, co
                      const LkArgs& a);
 
 // ---- matcher ------------------------------------------------------------------------------
-// Packed neighbour key: distance << 23 | train index (numeric order == (distance, index) order).
+// Packed neighbour key: distance << 22 | train index (numeric order == (distance, index) order).
+// 64-byte rows reach distance 512 = 2^9: 9 + 22 bits fit, and train indices stay below 2^22
+// (cv packs the image index above 18 bits, so its own limit is 262 144 rows).
 #define VO_KEY_INVALID 0xffffffffu
-#define VO_KEY_SHIFT 23
+#define VO_KEY_SHIFT 22
 struct KnnArgs {
     const uint32_t* q;    // descriptors, `words` uint32 per row
     const uint32_t* t;
@@ -164,21 +166,23 @@ struct KnnArgs {
     const int* d_n;       // optional device counts: nq = d_n[pair], nt = d_n[pair + 1]
     int nq, nt;           // used when d_n == nullptr; otherwise upper bounds for the grid
     int words;            // 8 (32-byte descriptors) or 16 (64-byte)
-    int splits;           // train range split across blockIdx.y
-    int qpl;              // queries per lane (1, 2 or 4; 64-byte rows: 1 or 2)
-    uint2* part;          // [pair][split][nq_cap] partial top-2 keys
-    uint2* knn;           // [pair][nq_cap] merged keys
-    int nq_cap;
+    int splits;           // train range split across blockIdx.y (1: the launch writes knn / rev itself)
+    int cross;            // also run the swapped direction (train rows as queries) into rev
+    uint2* part;          // [pair (+ npairs: reverse)][split][nq_cap] partial top-2 keys, splits > 1 only
+    uint2* knn;           // [pair][nq_cap] keys of the two nearest train rows of every query
+    uint2* rev;           // [pair][nq_cap] keys of the two nearest queries of every train row (cross only)
+    int nq_cap;           // row capacity of part / knn / rev (>= nq, and >= nt with cross)
     int npairs;
 };
-void launch_knn2_partial(hipStream_t st, const KnnArgs& a);
-void launch_knn2_merge(hipStream_t st, const KnnArgs& a);
+void launch_knn2(hipStream_t st, const KnnArgs& a);
+void launch_knn2_merge(hipStream_t st, const KnnArgs& a);  // no-op unless splits > 1
 
 struct GoodMatch {
     int q, t, dist, pad;
 };
 struct FilterArgs {
     const uint2* knn;          // [pair][nq_cap]
+    const uint2* rev;          // [pair][nq_cap] nearest queries of the train rows, or nullptr: no cross-check
     const vo_keypoint* kq;     // query keypoints of pair p at kq + p*kp_stride
     const vo_keypoint* kt;
     size_t kp_stride;          // in keypoints

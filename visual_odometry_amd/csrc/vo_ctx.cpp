@@ -144,7 +144,7 @@ void vo_pair_params_default(vo_pair_params* p, int nfeatures) {
     p->dist_thresh = 200.0;
     p->seed = ~(uint64_t)0;
     p->max_iters = 1000;
-    p->reserved = 0;
+    p->cross_check = 0;
 }
 
 int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
@@ -182,7 +182,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     DevBuf* dev[] = {&c->d_img,   &c->d_pyr,    &c->d_blur,  &c->d_score,  &c->d_masks, &c->d_segbase, &c->d_selcand, &c->d_selcnt, &c->d_flags,
                      &c->d_lvlofs, &c->d_cand,  &c->d_sel,   &c->d_coef,   &c->d_geom,   &c->d_kp,
-                     &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,
+                     &c->d_desc,  &c->d_nkp,    &c->d_q,     &c->d_t,      &c->d_part,   &c->d_knn,   &c->d_rev,
                      &c->d_good,  &c->d_ngood,  &c->d_p0,    &c->d_p1,     &c->d_kq,     &c->d_kt,
                      &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
                      &c->d_state, &c->d_mask,   &c->d_q4,    &c->d_cmask,  &c->d_pose,   &c->d_pmask,

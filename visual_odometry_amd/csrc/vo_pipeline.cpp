@@ -12,9 +12,9 @@
 #include "geom_types.h"
 
 int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q_stride, size_t t_stride,
-                   const int* d_n, int nq, int nt, int words, int npairs, int nq_cap);
+                   const int* d_n, int nq, int nt, int words, int npairs, int nq_cap, bool cross);
 int match_filter_dev(vo_ctx* c, const vo_keypoint* d_kq, const vo_keypoint* d_kt, size_t kp_stride,
-                     const int* d_n, int nq, int npairs, int nq_cap, float ratio, float max_disp);
+                     const int* d_n, int nq, int npairs, int nq_cap, float ratio, float max_disp, bool cross);
 
 
 
@@ -27,9 +27,9 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
         return c->fail(VO_ERR_CAPACITY, "%d keypoints per frame exceed max_points %d", n_cap, c->lim.max_points);
     const size_t kp_cap = (size_t)c->kp_cap;
     VO_TRY(match_knn2_dev(c, c->d_desc.as<uint32_t>(), c->d_desc.as<uint32_t>() + kp_cap * 8, kp_cap * 8,
-                          kp_cap * 8, c->d_nkp.as<int>(), max_n, max_n, 8, npairs, n_cap));
+                          kp_cap * 8, c->d_nkp.as<int>(), max_n, max_n, 8, npairs, n_cap, prm->cross_check != 0));
     VO_TRY(match_filter_dev(c, c->d_kp.as<vo_keypoint>(), c->d_kp.as<vo_keypoint>() + kp_cap, kp_cap,
-                            c->d_nkp.as<int>(), max_n, npairs, n_cap, prm->ratio, prm->max_disp));
+                            c->d_nkp.as<int>(), max_n, npairs, n_cap, prm->ratio, prm->max_disp, prm->cross_check != 0));
     VO_TRY(geom_prepare(c, npairs, n_cap, prm->seed, prm->max_iters));
     VO_TRY(geom_find_essential_dev(c, npairs, n_cap, c->d_p0.as<float2>(), c->d_p1.as<float2>(),
                                    c->d_ngood.as<int>(), 0, K, VO_RANSAC, prm->prob, prm->threshold,

@@ -133,20 +133,47 @@ def make_sequence(seq_id, n_frames, w=KITTI_W, h=KITTI_H, K=KITTI_K, workers=1):
     """Returns (frames uint8 (n,h,w), poses (n,3,4) camera-to-world, K).
 
     workers > 1 renders the frames in forked worker processes (same pixels; call it before the
-    process touches the GPU)."""
+    process touches the GPU).  With VO_SYNTH_CACHE=<dir> the rendered frames are kept there as .npy and
+    loaded on the next call: profiling runs (rocprofv3 preloads a library that initialises the GPU
+    before main, after which forking is not safe) render nothing and fork nothing."""
     global _render_job
-    world = World(seq_id)
     poses = trajectory(seq_id, n_frames)
-    if workers > 1 and n_frames > 8:
+    cache = os.environ.get("VO_SYNTH_CACHE")
+    path = None
+    if cache:
+        path = os.path.join(cache, "seq%d_%d_%dx%d_%x.npy" % (seq_id, n_frames, w, h,
+                                                                 abs(hash(tuple(np.round(K, 6).reshape(-1)))) & 0xffffff))
+        if os.path.exists(path):
+            return np.load(path), poses, K.copy()
+    world = World(seq_id)
+    if workers > 1 and n_frames > 8 and os.environ.get("VO_SYNTH_NOFORK", "0") != "1":
         import multiprocessing as mp
 
         _render_job = (world, poses, K, w, h)
-        with mp.get_context("fork").Pool(workers) as pool:
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             frames = np.stack(pool.map(_render_one, range(n_frames), chunksize=4))
+        finally:
+            pool.close()  # workers exit by themselves: no SIGTERM (terminate()) for a profiler to report
+            pool.join()
         _render_job = None
     else:
         frames = np.stack([world.render(poses[k], K, w, h) for k in range(n_frames)])
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        tmp = path + ".%d.tmp.npy" % os.getpid()
+        np.save(tmp, frames)
+        os.replace(tmp, path)
     return frames, poses, K.copy()
+
+
+def pingpong_indices(n_base, n_frames):
+    """Frame k of a long sequence cut from n_base rendered frames: 0, 1, .., n_base-1, n_base-2, .., 1, 0,
+    1, ..  Every consecutive pair is a pair of neighbouring base frames (forward or backward motion), so
+    a sequence of any length has the statistics of the rendered one without rendering it whole."""
+    period = 2 * (n_base - 1)
+    k = np.arange(n_frames) % period
+    return np.where(k < n_base, k, period - k).astype(np.int64)
 
 
 def write_kitti_layout(root, seq_id, frames, poses, K=KITTI_K):
