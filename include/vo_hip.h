@@ -109,6 +109,17 @@ int vo_match_filter_cross(vo_ctx* ctx, const vo_dmatch* knn, const int* n_valid,
                           int nt, const vo_keypoint* kq, const vo_keypoint* kt, float ratio, float max_disp,
                           vo_dmatch* good, int* n_good);
 
+/* knnMatch(k = 2) for callers that cannot allocate.  NO counterpart in the reference: it exists for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same results as
+ * vo_knn2_hamming, but: d_q / d_t / d_out are DEVICE pointers (16-byte aligned), rows are exactly 32 or
+ * 64 bytes, nq and nt are at most 8192 (VO_ERR_CAPACITY beyond), d_out is nq x 2 vo_dmatch (missing
+ * neighbours: trainIdx -1, distance FLT_MAX).  The call allocates nothing: its partial and merged keys
+ * live in a 0.81 MiB static device array that every GPU the library runs on holds until the process
+ * ends.  It only queues work on the context's stream: results are valid after vo_ctx_synchronize(ctx).
+ * All calls on one GPU share that array, so calls that overlap on one GPU (two contexts) race. */
+int vo_knn2_hamming_static(vo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int desc_bytes,
+                           vo_dmatch* d_out);
+
 /* ---- sfm: replaces the cv calls in updatePose() and matcher() ---------------------------- */
 
 /* cv::findEssentialMat(p0, p1, K, method, prob, threshold, mask)

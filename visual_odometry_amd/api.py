@@ -178,6 +178,11 @@ class VoContext:
         self._check(self.L.vo_knn2_hamming_cross(self.h, _p(q), nq, _p(t), nt, d, _p(out), _p(nv), _p(rev)))
         return out, nv[:nq], rev[:nt]
 
+    def knn2_hamming_static(self, d_q, nq, d_t, nt, desc_bytes, d_out):
+        """Device addresses in and out, no allocation, asynchronous on the context's stream."""
+        self._check(self.L.vo_knn2_hamming_static(self.h, C.c_void_p(int(d_q)), int(nq), C.c_void_p(int(d_t)), int(nt),
+                                                  int(desc_bytes), C.c_void_p(int(d_out))))
+
     def match_filter(self, knn, n_valid, kq, kt, ratio=0.7, max_disp=200.0, rev_nn=None):
         knn = np.ascontiguousarray(knn, DM_DTYPE)
         nq = knn.shape[0]

@@ -14,7 +14,7 @@
 //   entry point): lexicographic merge of the per-split keys.
 // k_match_filter: ratio test + displacement gate (+ optional cross-check) + order-preserving compaction.
 // Reference: src/matcher/matcher.cpp:17-38; SURVEY.md A.3.
-#include "kernels.h"
+#include "ctx.h"
 
 #define KNN_IDX_MASK ((1u << VO_KEY_SHIFT) - 1u)
 #define KNN_GROUP 64  // rows whose (distance << 6 | row) keys fit 16 bits: local top-2 by 16-bit min / max
@@ -347,4 +347,84 @@ __global__ __launch_bounds__(1024) void k_match_filter(FilterArgs a) {
 void launch_match_filter(hipStream_t st, const FilterArgs& a) {
     if (a.npairs <= 0) return;
     hipLaunchKernelGGL(k_match_filter, dim3(a.npairs), dim3(1024), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// vo_knn2_hamming_static: the 2-NN of one descriptor pair for callers that cannot allocate (HIP graph
+// capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+// Device pointers in and out; the per-split partial keys and the merged keys, which the ordinary entry
+// point keeps in the context's grow-only workspace, live in the file-scope array below, so the call
+// makes no hipMalloc / hipFree and no allocating library call.  Every GPU holds its own copy of the array
+// at its own address: knn_static_init() (called from vo_ctx_create with that device current) asks for it
+// once per device with hipGetSymbolAddress; host code only ever uses that pointer, never the array's name.
+// All calls on one GPU share the array: calls that overlap on one GPU race (one context, or calls
+// serialised by the caller).  Nothing needs clearing between calls: every word a call reads was written
+// by that call (k_knn2 writes all nq rows of every split, also for an empty train range).
+// ---------------------------------------------------------------------------------------------
+#define KNN_STATIC_MAX_SPLITS 12
+static __device__ __align__(256) uint2 scratch[(size_t)(KNN_STATIC_MAX_SPLITS + 1) * VO_KNN_STATIC_MAX];
+#define KNN_STATIC_MAX_DEVICES 64
+static uint2* g_scratch_ptr[KNN_STATIC_MAX_DEVICES];  // per device: address of that device's copy
+
+int knn_static_init(int device) {  // the caller has made `device` current
+    if (device < 0 || device >= KNN_STATIC_MAX_DEVICES) return VO_ERR_INVALID;
+    if (g_scratch_ptr[device]) return VO_OK;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return VO_ERR_DEVICE;
+    g_scratch_ptr[device] = static_cast<uint2*>(p);
+    return VO_OK;
+}
+
+__global__ __launch_bounds__(256) void k_keys_to_dmatch(const uint2* keys, int nq, vo_dmatch* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const uint2 k = keys[i];
+    const uint32_t key[2] = {k.x, k.y};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        vo_dmatch m;
+        m.queryIdx = i;
+        m.imgIdx = 0;
+        m.trainIdx = key[j] != VO_KEY_INVALID ? (int)(key[j] & KNN_IDX_MASK) : -1;
+        m.distance = key[j] != VO_KEY_INVALID ? (float)(key[j] >> VO_KEY_SHIFT) : 3.402823466e+38F;
+        out[(size_t)i * 2 + j] = m;
+    }
+}
+
+int knn_splits(int nq, int nt, int npairs, int dirs);  // vo_match.cpp
+
+extern "C" int vo_knn2_hamming_static(vo_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
+                                      int desc_bytes, vo_dmatch* d_out) {
+    if (!c) return VO_ERR_INVALID;
+    if (nq < 0 || nt < 0 || (desc_bytes != 32 && desc_bytes != 64) || (nq > 0 && (!d_q || !d_out)) ||
+        (nt > 0 && !d_t) || ((uintptr_t)d_q & 15) || ((uintptr_t)d_t & 15) || ((uintptr_t)d_out & 3))
+        return c->fail(VO_ERR_INVALID, "vo_knn2_hamming_static: bad argument (rows of exactly 32 or 64 bytes, "
+                                       "16-byte aligned device pointers)");
+    if (nq > VO_KNN_STATIC_MAX || nt > VO_KNN_STATIC_MAX)
+        return c->fail(VO_ERR_CAPACITY, "vo_knn2_hamming_static: %d x %d exceeds the static workspace (%d rows a side)",
+                       nq, nt, VO_KNN_STATIC_MAX);
+    VO_HIP(c, hipSetDevice(c->device));
+    uint2* ws = c->device < KNN_STATIC_MAX_DEVICES ? g_scratch_ptr[c->device] : nullptr;
+    if (!ws) return c->fail(VO_ERR_DEVICE, "vo_knn2_hamming_static: no static workspace on device %d", c->device);
+    if (nq == 0) return VO_OK;
+    KnnArgs a;
+    a.q = reinterpret_cast<const uint32_t*>(d_q);
+    a.t = reinterpret_cast<const uint32_t*>(d_t);
+    a.q_stride = a.t_stride = 0;
+    a.d_n = nullptr;
+    a.nq = nq;
+    a.nt = nt;
+    a.words = desc_bytes / 4;
+    a.splits = knn_splits(nq, nt, 1, 1);
+    if (a.splits > KNN_STATIC_MAX_SPLITS) a.splits = KNN_STATIC_MAX_SPLITS;
+    a.cross = 0;
+    a.knn = ws;                         // [VO_KNN_STATIC_MAX] merged keys
+    a.part = ws + VO_KNN_STATIC_MAX;    // [splits][VO_KNN_STATIC_MAX] partial keys
+    a.rev = nullptr;
+    a.nq_cap = VO_KNN_STATIC_MAX;
+    a.npairs = 1;
+    launch_knn2(c->stream, a);
+    launch_knn2_merge(c->stream, a);
+    hipLaunchKernelGGL(k_keys_to_dmatch, dim3(cdiv(nq, 256)), dim3(256), 0, c->stream, ws, nq, d_out);
+    return vo_check_launch(c, "knn2 (static workspace)");
 }

@@ -174,6 +174,8 @@ struct KnnArgs {
     int nq_cap;           // row capacity of part / knn / rev (>= nq, and >= nt with cross)
     int npairs;
 };
+#define VO_KNN_STATIC_MAX 8192  // rows a side of vo_knn2_hamming_static (include/vo_hip.h documents it)
+int knn_static_init(int device);  // address of this device's static matcher workspace (k_match.hip)
 void launch_knn2(hipStream_t st, const KnnArgs& a);
 void launch_knn2_merge(hipStream_t st, const KnnArgs& a);  // no-op unless splits > 1
 

@@ -154,6 +154,7 @@ int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VO_ERR_DEVICE;  // no CPU fallback
     if (device < 0 || device >= ndev) return VO_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return VO_ERR_DEVICE;
+    if (knn_static_init(device) != VO_OK) return VO_ERR_DEVICE;  // vo_knn2_hamming_static's workspace on this device
     vo_ctx* c = new vo_ctx();
     c->device = device;
     c->err[0] = 0;

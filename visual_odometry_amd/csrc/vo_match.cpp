@@ -9,7 +9,7 @@
 // batched path's shape (48 pairs x 2000 queries) with no split at all.  A single small problem is cut
 // along the train range until the chip is about that full (every wave keeps >= 64 rows) and merged by
 // k_knn2_merge.
-static int knn_splits(int nq, int nt, int npairs, int dirs) {
+int knn_splits(int nq, int nt, int npairs, int dirs) {
     const int blocks = cdiv(std::max(nq, 1), 64) * std::max(npairs, 1) * dirs;
     int s = (1536 + blocks / 2) / blocks;
     s = std::min(s, std::max(nt, 1) / 256);
