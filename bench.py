@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — frame-pairs/s of the per-frame-pair hot path on N MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1], batched): consecutive synthetic KITTI-shaped 1241x376 gray
-frames, ORB nfeatures=2000 detect+describe on every frame, brute-force Hamming 2-NN + ratio 0.7 +
-200 px gate between consecutive frames, findEssentialMat(RANSAC, 0.999, 1.0, seed (uint64)-1),
-recoverPose(200).  A step = one pass of vo_seq_run() over `--frames` frames (frames-1 frame pairs)
-already resident in HBM: the sequence runner cuts them into chunks of `--chunk` pairs and keeps
-`--streams` chunks in flight on separate HIP streams (each chunk is one vo_pairs_run_dev batch).  With N > 1 every rank runs its own
-synthetic sequence (sequences are the shard unit, no data-path collective; weak scaling) and the
-trajectories are gathered with one all_gather over RCCL after the timed region.
+N = 1 (BASELINE.json configs[3]): one seq-00-shaped sequence, 4541 synthetic KITTI-shaped 1241x376 gray
+frames resident in HBM, through vo_seq_run_ex(): ORB nfeatures=2000 detect+describe on every frame,
+brute-force Hamming 2-NN + ratio 0.7 + 200 px gate between consecutive frames, findEssentialMat(RANSAC,
+0.999, 1.0, seed (uint64)-1), recoverPose(200); chunks of `--chunk` pairs on `--streams` HIP streams; the
+per-pair results, filtered matches, inlier masks and pose masks come back to the host inside the timed
+region.  A step = one pass over the whole sequence (4540 frame pairs).
 
-Prints ONE JSON line on rank 0.  `roofline` is the matcher kernel under the O(N^2) scan model of
-SURVEY.md §8(d) (nq*nt*32 + nq*32 + nq*16 bytes per pair), timed live with HIP events on the
-library's stream; `cpu_baseline` is the CPU oracle (a port) on the host cores on a bounded sample.
+N > 1 (configs[4]): the 22 KITTI-shaped sequences (lengths: reference src/kitti/readme.txt:125-135 for
+00-10, SURVEY.md 8d for 11-21) are assigned to the ranks by longest-processing-time-first
+(visual_odometry_amd/shard.py), every rank runs its sequences the same way, no data-path collective; the
+trajectories are gathered over RCCL after the timed region.  Total work is fixed: strong scaling.
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU) unless a launcher
+(torch.distributed.run) already did.
+
+Frames: one `--base-frames`-frame sequence is rendered per rank (visual_odometry_amd/synth.py) and the long
+sequences are cut from it back and forth (0..B-1, B-2..1, 0..), so every consecutive pair is a pair of
+neighbouring rendered frames; every frame of the long sequence is its own 466 616 bytes in HBM.
+
+Prints ONE JSON line on rank 0.  `roofline` is the matcher kernel against its VALU issue bound (DESIGN.md
+4: nothing else bounds it, the train rows sit in SGPRs); `cpu_baseline` is the optimised CPU port
+(cpu_baseline/) on the host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,26 +38,111 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# VALU issue bound of the matcher row (tools/micro/valu_table.hip -> profiles/r2_valu_table.txt): cycles per
+# wave64 instruction on one SIMD; per (64 queries x 1 train row): 8 v_xor + 8 v_bcnt + 1 v_lshl_or +
+# v_max_u16 + 2 v_min_u16.
+CYC_FAST, CYC_SLOW = 2.3, 4.15
+ROW_CYCLES = 8 * CYC_FAST + 8 * CYC_SLOW + CYC_SLOW + 3 * CYC_FAST
+SIMDS, CLOCK_GHZ = 1024, 2.4
+
+
+def valu_ceiling_tpairs():
+    return SIMDS * CLOCK_GHZ * 1e9 * 64 / ROW_CYCLES / 1e12
+
 
 def scan_bytes(nq, nt):
     return nq * nt * 32 + nq * 32 + nq * 16
 
 
-def cpu_baseline(frames, K, nfeatures, max_iters=1000, budget_s=12.0):
-    """The oracle's restatement of the same path on the host cores: frame pairs are independent on this
-    path, so worker threads (ctypes releases the GIL inside the oracle) take pairs off a shared counter
-    until the time budget is spent.  value = pairs finished / wall time with `cores` threads; the
-    per-thread rate of the same run is reported next to it."""
-    import threading
+def compulsory_bytes(nq, nt):
+    return (nq + nt) * 32 + nq * 16
+
+
+# ---------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks (fresh processes, before anything touched the GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def cpu_port():
+    """The optimised CPU port (cpu_baseline/libvo_cpu.so, x86-64-v3) bound through oracle/pyoracle.py's
+    ctypes wrappers; the plain oracle build if the host CPU lacks AVX2 / BMI2 / POPCNT."""
+    import importlib.util
 
     from oracle import pyoracle as o
 
+    path = os.path.join(ROOT, "cpu_baseline", "libvo_cpu.so")
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        flags = ""
+    if not os.path.exists(path) or not all(f in flags for f in (" avx2", " bmi2", " popcnt", " fma")):
+        return o, "oracle/ (-O2, byte-wise popcount: cpu_baseline/ unavailable on this host)"
+    spec = importlib.util.spec_from_file_location("pyoracle_cpu_baseline", o.__file__)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m._LIB_PATH = path
+    return m, "cpu_baseline/ (-O3 x86-64-v3, 64-bit popcount matcher, early-reject FAST, vectorised blur)"
+
+
+def cpu_baseline(frames, K, nfeatures, max_iters=1000, budget_s=10.0, reps=20):
+    """The same path on the host cores.  Per stage: median and min of `reps` single-thread repetitions after
+    3 warm-ups.  Throughput: frame pairs are independent on this path, so worker threads
+    (ctypes releases the GIL) take pairs off a shared counter until the budget is spent; value = pairs
+    finished / wall time with `cores` threads."""
+    import threading
+
+    o, what = cpu_port()
     po = o.orb_params(nfeatures)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return {"median_ms": float(np.median(ts)) * 1e3, "min_ms": float(np.min(ts)) * 1e3}
+
+    k0, d0 = o.orb_detect_compute(frames[0], po)
+    k1, d1 = o.orb_detect_compute(frames[1], po)
+    knn, nv = o.knn2_hamming(d0, d1)
+    good = o.match_filter(knn, nv, k0, k1, 0.7, 200.0)
+    p0 = np.stack([k0["x"][good["queryIdx"]], k0["y"][good["queryIdx"]]], 1)
+    p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
+    rc, E, mask, _ = o.find_essential(p0, p1, K, o.RANSAC, max_iters=max_iters)
+    stages = {
+        "orb_detect_compute_per_frame": timed(lambda: o.orb_detect_compute(frames[0], po)),
+        "knn2_hamming_per_pair": timed(lambda: o.knn2_hamming(d0, d1)),
+        "match_filter_per_pair": timed(lambda: o.match_filter(knn, nv, k0, k1, 0.7, 200.0)),
+        "find_essential_ransac_per_pair": timed(lambda: o.find_essential(p0, p1, K, o.RANSAC, max_iters=max_iters)),
+        "recover_pose_per_pair": timed(lambda: o.recover_pose(E, p0, p1, K, 200.0, mask)) if rc == 0 else None,
+    }
+
     cores = max(1, min(16, os.cpu_count() or 1, len(frames) - 1))
     t0 = time.perf_counter()
     lock = threading.Lock()
     state = {"next": 0, "done": 0, "busy_s": 0.0}
-
     feats = [None] * len(frames)
     ready = [threading.Event() for _ in frames]
 
@@ -61,14 +157,14 @@ def cpu_baseline(frames, K, nfeatures, max_iters=1000, budget_s=12.0):
             describe(0)
         describe(i + 1)
         ready[i].wait()
-        (k0, d0), (k1, d1) = feats[i], feats[i + 1]
-        knn, nv = o.knn2_hamming(d0, d1)
-        good = o.match_filter(knn, nv, k0, k1, 0.7, 200.0)
-        p0 = np.stack([k0["x"][good["queryIdx"]], k0["y"][good["queryIdx"]]], 1)
-        p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
-        rc, E, mask, _ = o.find_essential(p0, p1, K, o.RANSAC, max_iters=max_iters)
-        if rc == 0:
-            o.recover_pose(E, p0, p1, K, 200.0, mask)
+        (a0, b0), (a1, b1) = feats[i], feats[i + 1]
+        kn, v = o.knn2_hamming(b0, b1)
+        g = o.match_filter(kn, v, a0, a1, 0.7, 200.0)
+        q0 = np.stack([a0["x"][g["queryIdx"]], a0["y"][g["queryIdx"]]], 1)
+        q1 = np.stack([a1["x"][g["trainIdx"]], a1["y"][g["trainIdx"]]], 1)
+        r, Em, m, _ = o.find_essential(q0, q1, K, o.RANSAC, max_iters=max_iters)
+        if r == 0:
+            o.recover_pose(Em, q0, q1, K, 200.0, m)
 
     def worker():
         while True:
@@ -90,45 +186,74 @@ def cpu_baseline(frames, K, nfeatures, max_iters=1000, budget_s=12.0):
         t.join()
     dt = time.perf_counter() - t0
     pairs = state["done"]
-    return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+    return {"value": pairs / dt, "unit": "frame-pairs/s", "cores": cores, "kind": "port", "build": what,
             "per_thread_value": pairs / state["busy_s"] if state["busy_s"] > 0 else None,
-            "sample": "%d frame pairs of the same batch (ORB once per frame), oracle/ on %d threads for %.1f s"
-                      % (pairs, cores, dt)}
+            "stages_single_thread": stages, "stage_reps": reps,
+            "sample": "%d frame pairs of the rendered base sequence (ORB once per frame) on %d threads for %.1f s; "
+                      "per-stage medians of %d single-thread repetitions" % (pairs, cores, dt, reps)}
 
 
+# ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=3, help="chunks in flight (HIP streams)")
     ap.add_argument("--chunk", type=int, default=48, help="frame pairs per chunk")
-    ap.add_argument("--frames", type=int, default=0, help="frames per step (default 6 chunks: 6*chunk + 1)")
+    ap.add_argument("--frames", type=int, default=4541, help="frames of the N = 1 sequence (seq 00: 4541)")
+    ap.add_argument("--base-frames", type=int, default=289, help="rendered frames the long sequences are cut from")
     ap.add_argument("--nfeatures", type=int, default=2000)
     ap.add_argument("--max-iters", type=int, default=1000,
                     help="RANSAC hypothesis cap (cv: 1000; BASELINE configs[2] stress: 4096 with --nfeatures 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the frames-in-pinned-host-memory side measurement")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: launch, sharding, barriers and the trajectory gather only (CPU plumbing test)")
     args = ap.parse_args()
 
-    if args.frames <= 0:
-        args.frames = 6 * args.chunk + 1  # two rounds of chunks per stream: the pipeline reaches steady state
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (it starts the "
+                         "ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`\n"
+                         % (args.gpus, world))
+        sys.exit(2)
 
-    # ---- synthetic input: each rank renders its own sequence (the shard unit); rendered in forked
-    # workers before anything touches the GPU ------------------------------------------------------
-    from visual_odometry_amd import synth
+    from visual_odometry_amd import shard, synth
 
-    frames, poses, K = synth.make_sequence(rank, args.frames, workers=max(1, min(8, 16 // max(world, 1))))
+    # ---- which sequences this rank runs ---------------------------------------------------------------
+    if world == 1:
+        my_seqs = [(0, args.frames)]
+        lengths = [args.frames]
+        imbalance = 1.0
+    else:
+        lengths = list(shard.KITTI_LENGTHS)
+        assign = shard.lpt_assign(lengths, world)
+        my_seqs = [(i, lengths[i]) for i in assign[rank]]
+        loads = [sum(lengths[i] - 1 for i in a) for a in assign]
+        imbalance = max(loads) / (sum(loads) / world)
+    total_pairs_per_step = sum(n - 1 for n in lengths)
+    lmax = max([n for _, n in my_seqs] + [2])
+
+    # ---- synthetic input: rendered in forked workers before anything touches the GPU -------------------
+    base_n = max(2, min(args.base_frames, lmax))
+    if args.dry_run:
+        frames = None
+        K = synth.KITTI_K.copy()
+    else:
+        frames, _, K = synth.make_sequence(rank, base_n, workers=max(1, min(8, 16 // max(world, 1))))
+    idx = synth.pingpong_indices(base_n, lmax)
 
     import torch
 
     # VO_BENCH_REHEARSE=1: every rank on GPU 0 and gloo instead of RCCL, to rehearse the multi-rank path
-    # (barriers, max over ranks, trajectory gather, rank-0 report) on a one-GPU box.  Not a measurement.
-    rehearse = os.environ.get("VO_BENCH_REHEARSE", "0") == "1"
+    # (launch, LPT shards, barriers, max over ranks, trajectory gather, rank-0 report) on a one-GPU box.
+    rehearse = os.environ.get("VO_BENCH_REHEARSE", "0") == "1" or args.dry_run
     if rehearse:
         local_rank = 0
     dist = None
@@ -140,138 +265,201 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cdev = torch.device("cpu") if rehearse else torch.device("cuda", local_rank)  # where the collectives' tensors live
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    if args.dry_run:
+        # plumbing only: identity poses stand in for the results
+        barrier()
+        t0 = time.perf_counter()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        local = {sid: shard.chain_poses([(1, None, None)] * (n - 1), n) for sid, n in my_seqs}
+        all_traj = shard.gather_trajectories(local, dist, cdev) if dist is not None else local
+        assert sorted(all_traj) == list(range(len(lengths))) and all(len(all_traj[i]) == lengths[i] for i in all_traj)
+        if rank == 0:
+            print(json.dumps({"metric": "frame-pairs/sec (1241x376, 2k ORB)", "value": None, "unit": "frame-pairs/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "scaling": "strong", "lpt_imbalance": imbalance, "sequences": len(lengths),
+                              "trajectories_gathered": len(all_traj), "pairs_per_step": total_pairs_per_step,
+                              "timed_region_s": elapsed}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = torch.device("cpu") if rehearse else dev  # where the collectives' tensors live
+    from visual_odometry_amd import api
 
-    from visual_odometry_amd import api, shard
-
-    n, h, w = frames.shape
-    d_frames = torch.from_numpy(frames).to(dev)
+    _, h, w = frames.shape
+    d_base = torch.from_numpy(frames).to(dev)
+    d_seq = d_base.index_select(0, torch.from_numpy(idx).to(dev))  # (lmax, h, w): every frame its own bytes
+    del d_base
     torch.cuda.synchronize()
 
     seq = api.VoSequence(local_rank, n_streams=args.streams, pairs_per_chunk=args.chunk)
     ctx = seq.ctx(0)
     params = api.pair_params(args.nfeatures, max_iters=args.max_iters)
+    cap = min(ctx.limits.max_points, args.nfeatures + args.nfeatures // 8 + 64)  # matches per pair <= keypoints per frame
+    out_m = np.zeros((lmax - 1, cap), api.DM_DTYPE)
+    out_im = np.zeros((lmax - 1, cap), np.uint8)
+    out_pm = np.zeros((lmax - 1, cap), np.uint8)
+
+    def run_seq(ptr, n, mem=api.MEM_DEVICE):
+        return seq.run(ptr, n, w, h, w, w * h, K, params, mem=mem,
+                       outputs=(out_m[: n - 1], out_im[: n - 1], out_pm[: n - 1]))
 
     def step():
-        return seq.run(d_frames.data_ptr(), n, w, h, w, w * h, K, params)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        return [run_seq(d_seq.data_ptr(), n) for _, n in my_seqs]
 
     for _ in range(args.warmup):
         res = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()  # synchronous on return: results are on the host
+        res = step()  # synchronous on return: results, matches and masks are on the host
+    busy = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     seq_stats = seq.stats()
+    rank_busy = [busy]
     if dist is not None:
-        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    pairs_per_step = n - 1
-    total_pairs = world * args.steps * pairs_per_step
+        t = torch.tensor([elapsed, busy], device=cdev, dtype=torch.float64)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        elapsed = max(float(x[0]) for x in ts)
+        rank_busy = [float(x[1]) for x in ts]
+    total_pairs = args.steps * total_pairs_per_step
 
-    # ---- chain the relative poses into a trajectory on the host, gather over RCCL --------------
-    traj = shard.chain_poses([(res[p].status, np.array(res[p].R), np.array(res[p].t)) for p in range(n - 1)], n)
+    # ---- chain the relative poses into trajectories on the host, gather over RCCL ----------------------
+    local = {}
+    for (sid, n), r in zip(my_seqs, res):
+        local[sid] = shard.chain_poses([(r[p].status, np.array(r[p].R), np.array(r[p].t)) for p in range(n - 1)], n)
+    all_traj = local
     if dist is not None:
-        all_traj = shard.gather_trajectories({rank: traj}, dist, cdev)
+        all_traj = shard.gather_trajectories(local, dist, cdev)
         torch.cuda.synchronize()
-        assert len(all_traj) == world
+    assert sorted(all_traj) == list(range(len(lengths)))
 
-    # ---- roofline: matcher kernel, HIP events on the library's stream (untimed passes) ----------
-    # one chunk at a time on context 0, so that the matcher launch is timed without other streams
-    # sharing the chip (the rocprofv3 summary in profiles/ is taken with --streams 1 for the same reason)
-    nkp = [res[0].n_kp0] + [res[p].n_kp1 for p in range(n - 1)]
-    nc = min(args.chunk, n - 1)  # pairs per matcher launch
-    algo_bytes = sum(scan_bytes(nkp[p], nkp[p + 1]) for p in range(nc))
-    ctx.prof_enable(True)
-    for which in (0, 1, 2, 3):
-        ctx.prof_get(which, True)
-    for _ in range(5):
-        ctx.pairs_run_dev(d_frames.data_ptr(), nc + 1, w, h, w, w * h, K, params)
-    knn_n, knn_ms = ctx.prof_get(0)
-    fast_n, fast_ms = ctx.prof_get(1)
-    solve_n, solve_ms = ctx.prof_get(2)
-    feat_n, feat_ms = ctx.prof_get(3)
-    ctx.prof_enable(False)
-    # detector + descriptor stage (pyramid .. rBRIEF) against its algorithmic bytes (SURVEY.md 8d:
-    # W*H + 4*P + K*60 per frame, P = pyramid pixels): HBM-bound in the limit, VALU / latency bound today
-    pyr_px = sum(int(round(w / 1.2 ** l)) * int(round(h / 1.2 ** l)) for l in range(8))
-    feat_bytes = sum(w * h + 4 * pyr_px + k * 60 for k in nkp[: nc + 1])
-    feat_s = feat_ms / max(feat_n, 1) * 1e-3
-    detector = {"stage": "pyramid + FAST/NMS + selection + IC angle + blur + rBRIEF, %d frames per batch" % (nc + 1),
-                "bound": "hbm", "achieved": feat_bytes / feat_s / 1e9 if feat_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": feat_bytes / feat_s / 1e9 / HBM_PEAK_GBS if feat_s > 0 else 0.0,
-                "algorithmic_bytes_per_batch": feat_bytes, "avg_batch_us": feat_s * 1e6}
-    knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
-    achieved = algo_bytes / knn_avg_s / 1e9 if knn_avg_s > 0 else 0.0
-    traffic = None
-    # HBM bytes per launch from the committed PMC passes (tools/gpu_profile.sh -> profiles/)
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
-        try:
-            kern = json.load(open(pmc_path))["kernels"]
-            traffic = [v for k, v in kern.items() if k.startswith("k_knn2_partial")][0]["hbm_bytes"]
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "k_knn2_partial<8, 1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "model": "O(N^2) scan model: nq*nt*32 + nq*32 + nq*16 bytes per pair (SURVEY.md 8d)",
-                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": knn_avg_s * 1e6,
-                "pairs_per_launch": nc}
-    # The tiles live in LDS, so the scan-model figure exceeds the HBM peak; the kernel's real ceiling is the
-    # VALU one: 8 xor + 8 half-rate bcnt + key pack + min/max/min = 28 issue slots per
-    # descriptor pair at the measured ~76 T lane-ops/s of the chip -> ~2.7 T descriptor pairs/s.
-    desc_pairs = sum(nkp[p] * nkp[p + 1] for p in range(nc))
-    roofline["valu"] = {"achieved_Tpairs_s": desc_pairs / knn_avg_s / 1e12, "ceiling_Tpairs_s": 2.7,
-                        "frac": desc_pairs / knn_avg_s / 2.7e12}
+    r0 = res[0]
+    n0 = my_seqs[0][1]
+    ok = sum(1 for r, (_, n) in zip(res, my_seqs) for p in range(n - 1) if r[p].status == 0)
+    nkp = [r0[0].n_kp0] + [r0[p].n_kp1 for p in range(n0 - 1)]
+    # the downloaded tables are the real ones: inlier counts of the last sequence run agree with its results
+    rl, nl = res[-1], my_seqs[-1][1]
+    for p in (0, nl // 2, nl - 2):
+        assert int(out_im[p, : rl[p].n_good].sum()) == rl[p].n_inliers and int(out_pm[p, : rl[p].n_good].sum()) == rl[p].n_pose
 
-    # ---- the same steps with the frames in pinned host memory: every chunk crosses PCIe inside the timed
-    # region (the copy of one chunk overlaps the kernels of the others).  Reported beside `value`, never as it.
-    pcie = None
-    if rank == 0 and world == 1:
-        pinned = torch.from_numpy(frames).pin_memory()
-        seq.run(pinned.data_ptr(), n, w, h, w, w * h, K, params, mem=api.MEM_HOST_PINNED)
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for _ in range(args.steps):
-            seq.run(pinned.data_ptr(), n, w, h, w, w * h, K, params, mem=api.MEM_HOST_PINNED)
-        tp = time.perf_counter() - tp
-        pcie = {"value": args.steps * pairs_per_step / tp, "unit": "frame-pairs/s",
-                "note": "frames in pinned host memory, uploads inside the timed region"}
-        del pinned
-
-    # ---- 8k x 8k matcher (BASELINE config 3 shape), same accounting -----------------------------
-    matcher_8k = None
-    if rank == 0 and not args.no_8k:
-        q, t = synth.matcher_descriptors(8192)
-        for _ in range(2):
-            ctx.knn2_hamming(q, t)
-        ctx.prof_enable(True)
-        ctx.prof_get(0, True)
-        for _ in range(5):
-            ctx.knn2_hamming(q, t)
-        kn, kms = ctx.prof_get(0)
-        ctx.prof_enable(False)
-        avg = kms / max(kn, 1) * 1e-3
-        b8 = scan_bytes(8192, 8192)
-        matcher_8k = {"avg_launch_us": avg * 1e6, "achieved_GBs": b8 / avg / 1e9,
-                      "frac_of_hbm_peak": b8 / avg / 1e9 / HBM_PEAK_GBS,
-                      "algorithmic_bytes": b8, "compulsory_bytes": (8192 + 8192) * 32 + 8192 * 16}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frames, K, args.nfeatures, args.max_iters)
-
+    line = None
     if rank == 0:
-        ok = sum(1 for p in range(n - 1) if res[p].status == 0)
+        # ---- roofline: matcher kernel, HIP events on the library's stream (untimed passes) ------------
+        # one chunk at a time on context 0, so that the matcher launch is timed without other streams
+        # sharing the chip (the rocprofv3 summary in profiles/ is taken with --streams 1 for the same reason)
+        nc = min(args.chunk, n0 - 1)  # pairs per matcher launch
+        ctx.prof_enable(True)
+        for which in (0, 1, 2, 3):
+            ctx.prof_get(which, True)
+        for _ in range(5):
+            rb = ctx.pairs_run_dev(d_seq.data_ptr(), nc + 1, w, h, w, w * h, K, params)
+        knn_n, knn_ms = ctx.prof_get(0)
+        fast_n, fast_ms = ctx.prof_get(1)
+        solve_n, solve_ms = ctx.prof_get(2)
+        feat_n, feat_ms = ctx.prof_get(3)
+        ctx.prof_enable(False)
+        bkp = [rb[0].n_kp0] + [rb[p].n_kp1 for p in range(nc)]
+        knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
+        desc_pairs = sum(bkp[p] * bkp[p + 1] for p in range(nc))
+        ceiling = valu_ceiling_tpairs()
+        achieved = desc_pairs / knn_avg_s / 1e12 if knn_avg_s > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):  # HBM bytes per launch from the committed PMC passes (tools/gpu_profile.sh)
+            try:
+                kern = json.load(open(pmc_path))["kernels"]
+                traffic = [v for k, v in kern.items() if k.startswith("k_knn2")][0]["hbm_bytes"]
+            except Exception:
+                traffic = None
+        comp = sum(compulsory_bytes(bkp[p], bkp[p + 1]) for p in range(nc))
+        scan = sum(scan_bytes(bkp[p], bkp[p + 1]) for p in range(nc))
+        roofline = {
+            "kernel": "k_knn2<8>", "bound": "valu", "achieved": achieved, "peak": ceiling,
+            "unit": "T descriptor pairs/s", "frac": achieved / ceiling, "traffic": traffic,
+            "peak_model": "per 64 queries x 1 train row: 8 v_xor_b32 + 3 16-bit min/max at %.2f cycles, 8 v_bcnt_u32_b32 "
+                          "+ v_lshl_or_b32 at %.2f cycles (measured issue costs, profiles/r2_valu_table.txt) = %.1f "
+                          "cycles on each of %d SIMDs at %.1f GHz" % (CYC_FAST, CYC_SLOW, ROW_CYCLES, SIMDS, CLOCK_GHZ),
+            "avg_launch_us": knn_avg_s * 1e6, "pairs_per_launch": nc, "descriptor_pairs_per_launch": desc_pairs,
+            "compulsory_bytes_per_launch": comp,
+            "traffic_over_compulsory": traffic / comp if traffic else None,
+            "hbm": {"achieved_GBs": traffic / knn_avg_s / 1e9 if traffic and knn_avg_s > 0 else None,
+                    "peak_GBs": HBM_PEAK_GBS,
+                    "frac": traffic / knn_avg_s / 1e9 / HBM_PEAK_GBS if traffic and knn_avg_s > 0 else None},
+            "scan_model": {"note": "SURVEY.md 8d's O(N^2) model nq*nt*32 + nq*48 bytes per pair: not a bound (the "
+                                   "rows are re-read from registers, not from HBM), kept for reference only",
+                           "bytes_per_launch": scan, "GBs": scan / knn_avg_s / 1e9 if knn_avg_s > 0 else None},
+        }
+        # detector + descriptor stage (pyramid .. rBRIEF) against its algorithmic bytes (SURVEY.md 8d:
+        # W*H + 4*P + K*60 per frame, P = pyramid pixels): HBM-bound in the limit, VALU / latency bound today
+        pyr_px = sum(int(round(w / 1.2 ** l)) * int(round(h / 1.2 ** l)) for l in range(8))
+        feat_bytes = sum(w * h + 4 * pyr_px + k * 60 for k in bkp)
+        feat_s = feat_ms / max(feat_n, 1) * 1e-3
+        detector = {"stage": "pyramid + FAST/NMS + selection + IC angle + blur + rBRIEF, %d frames per batch" % (nc + 1),
+                    "bound": "hbm", "achieved": feat_bytes / feat_s / 1e9 if feat_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": feat_bytes / feat_s / 1e9 / HBM_PEAK_GBS if feat_s > 0 else 0.0,
+                    "algorithmic_bytes_per_batch": feat_bytes, "avg_batch_us": feat_s * 1e6}
+
+        # ---- the same sequence with the frames in pinned host memory: every chunk crosses PCIe inside the
+        # timed region (its copy overlaps the kernels of the other chunks).  Beside `value`, never as it.
+        pcie = None
+        if world == 1 and not args.no_pcie:
+            pinned = torch.from_numpy(frames[idx[:n0]]).pin_memory()
+            run_seq(pinned.data_ptr(), n0, api.MEM_HOST_PINNED)
+            torch.cuda.synchronize()
+            psteps = max(2, args.steps // 5)
+            tp = time.perf_counter()
+            for _ in range(psteps):
+                run_seq(pinned.data_ptr(), n0, api.MEM_HOST_PINNED)
+            tp = time.perf_counter() - tp
+            pcie = {"value": psteps * (n0 - 1) / tp, "unit": "frame-pairs/s", "steps": psteps,
+                    "note": "frames in pinned host memory: upload, kernels and the download of results, matches and "
+                            "masks all inside the timed region (SURVEY.md 8d's end-to-end definition)"}
+            del pinned
+
+        # ---- 8k x 8k matcher (BASELINE configs[2] shape), same accounting --------------------------------
+        matcher_8k = None
+        if not args.no_8k:
+            q, t = synth.matcher_descriptors(8192)
+            for _ in range(2):
+                ctx.knn2_hamming(q, t)
+            ctx.prof_enable(True)
+            ctx.prof_get(0, True)
+            for _ in range(5):
+                ctx.knn2_hamming(q, t)
+            kn, kms = ctx.prof_get(0)
+            ctx.prof_enable(False)
+            avg = kms / max(kn, 1) * 1e-3
+            matcher_8k = {"avg_launch_us": avg * 1e6, "achieved_Tpairs_s": 8192 * 8192 / avg / 1e12,
+                          "frac_of_valu_bound": 8192 * 8192 / avg / 1e12 / ceiling,
+                          "compulsory_bytes": compulsory_bytes(8192, 8192)}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(frames, K, args.nfeatures, args.max_iters)
+
+        if world == 1:
+            workload = ("configs[3]: one seq-00-shaped sequence of %d synthetic 1241x376 frames resident in HBM "
+                        "(cut back and forth from %d rendered frames), ORB nfeatures=%d + BF-Hamming knn2/ratio/gate + "
+                        "5-pt RANSAC + recoverPose per consecutive pair; chunks of %d pairs on %d HIP streams; per-pair "
+                        "results, matches, inlier and pose masks downloaded inside the timed region"
+                        % (n0, base_n, args.nfeatures, args.chunk, args.streams))
+        else:
+            workload = ("configs[4]: 22 KITTI-shaped sequences (%d frames, each cut back and forth from the rank's %d "
+                        "rendered frames) LPT-sharded over %d GPUs, per sequence as configs[3]; trajectories gathered "
+                        "over RCCL after the timed region" % (sum(lengths), base_n, world))
         line = {
             "metric": "frame-pairs/sec (1241x376, 2k ORB)",
             "value": total_pairs / elapsed,
@@ -281,30 +469,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "u8 features/descriptors, u64 popcount matching, f64 geometry",
+            "dtype": "u8 features/descriptors, u32 popcount matching, f64 geometry",
             "data": "synthetic (seeded planar-world KITTI-shaped frames rendered by visual_odometry_amd/synth.py)",
-            "config": {"workload": "configs[1] batched: %d consecutive 1241x376 frames per GPU resident in HBM, "
-                                   "ORB nfeatures=%d + BF-Hamming knn2/ratio/gate + 5-pt RANSAC + recoverPose per "
-                                   "consecutive pair; chunks of %d pairs on %d HIP streams"
-                                   % (n, args.nfeatures, args.chunk, args.streams),
-                       "frames_per_step": n, "pairs_per_step": pairs_per_step, "nfeatures": args.nfeatures,
-                       "ransac_max_iters": args.max_iters,
-                       "streams": args.streams, "pairs_per_chunk": args.chunk,
-                       "parallelism": "sequence shards x%d, no data-path collective" % world},
+            "config": {"workload": workload, "sequences": len(lengths), "frames_per_step": sum(lengths),
+                       "pairs_per_step": total_pairs_per_step, "nfeatures": args.nfeatures,
+                       "ransac_max_iters": args.max_iters, "streams": args.streams, "pairs_per_chunk": args.chunk,
+                       "rendered_base_frames": base_n,
+                       "parallelism": "sequence shards x%d (LPT by frame count), no data-path collective" % world},
+            "timed_region_s": elapsed,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
             "detector_roofline": detector,
             "pcie_inclusive": pcie,
-            "stage_us_per_step": {"fast_score_kernel": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
-                                  "knn2_partial_kernel": knn_avg_s * 1e6,
-                                  "solve5_kernels_per_step": solve_ms / 5 * 1e3},
-            "host_ms_last_step": {"chunks": seq_stats[0], "queueing": seq_stats[1], "waiting": seq_stats[2]},
+            "lpt_imbalance": imbalance,
+            "rank_busy_s": rank_busy,
+            "trajectories_gathered": len(all_traj),
+            "stage_us": {"fast_nms_kernel_per_batch": fast_ms / max(fast_n, 1) * 1e3 if fast_n else None,
+                         "knn2_kernel_per_batch": knn_avg_s * 1e6,
+                         "solve5_kernels_per_batch": solve_ms / 5 * 1e3,
+                         "features_per_batch": feat_s * 1e6},
+            "host_ms_last_sequence": {"chunks": seq_stats[0], "queueing": seq_stats[1], "waiting": seq_stats[2]},
             "pairs_with_pose": ok,
             "keypoints_per_frame": float(np.mean(nkp)),
         }
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(line))
     seq.close()
     if dist is not None:

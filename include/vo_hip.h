@@ -213,6 +213,22 @@ int vo_seq_get_stats(const vo_seq* s, int* chunks, double* submit_ms, double* wa
 int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
                size_t frame_stride, const double* K, const vo_pair_params* params, vo_pair_result* results);
 
+/* vo_seq_run plus the per-pair tables the reference's matcher() / updatePose() hand back: the filtered
+ * matches (MatchesInfo::matches, src/matcher/matcher.cpp:33), the RANSAC inlier mask
+ * (MatchesInfo::inliers_mask, :44-48) and recoverPose's mask (src/visual_odometry/vo_pose.h:19).
+ * HOST arrays of n_frames-1 rows of match_cap entries; row p holds results[p].n_good used entries.
+ * Any pointer may be NULL.  VO_ERR_CAPACITY if a pair has more than match_cap matches. */
+typedef struct vo_seq_outputs {
+    vo_dmatch* matches;
+    uint8_t* inlier_mask;
+    uint8_t* pose_mask;
+    int32_t match_cap;
+    int32_t reserved;
+} vo_seq_outputs;
+int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
+                  size_t frame_stride, const double* K, const vo_pair_params* params, vo_pair_result* results,
+                  const vo_seq_outputs* out);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------
  * When enabled, launches of the matcher kernel are bracketed with HIP events on the ctx stream;
  * vo_prof_get returns the number of launches and their summed duration since the last reset. */

@@ -76,6 +76,7 @@ struct FastPt {
     int x, y, score;
 };
 
+#ifndef VO_CPU_BASELINE  // cpu_baseline/ replaces this definition by an optimised one with equal results
 static void fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, bool nms,
                      std::vector<FastPt>& out) {
     out.clear();
@@ -111,6 +112,8 @@ static void fast9_16(const uint8_t* img, int w, int h, int stride, int threshold
         }
     }
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------
 // resize INTER_LINEAR_EXACT, 8-bit: ufixedpoint16 (8 fractional bits) coefficients,
@@ -200,6 +203,7 @@ static inline int reflect101(int i, int n) {
     return i;
 }
 
+#ifndef VO_CPU_BASELINE  // see fast9_16
 static void gauss7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
     int taps[7];
     gauss7_taps(taps);
@@ -222,6 +226,10 @@ static void gauss7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, 
         }
     }
 }
+
+#else
+#include "../cpu_baseline/cpu_kernels.inc"
+#endif
 
 // ---------------------------------------------------------------------------------------
 // ORB

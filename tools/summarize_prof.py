@@ -62,6 +62,20 @@ def main():
     shutil.copy(p, os.path.join(dst, "pmc_latest.json"))
     for k, v in out["kernels"].items():
         print("%-28s n=%4d fetch=%12.0f write=%12.0f" % (k, v["launches"], v["fetch_bytes"] or 0, v["write_bytes"] or 0))
+    # SQ pass: per kernel means per launch (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles)
+    sq_path = os.path.join(src, "pmc_sq", "sq_counter_collection.csv")
+    if os.path.exists(sq_path):
+        agg = defaultdict(lambda: defaultdict(list))
+        with open(sq_path) as f:
+            for row in csv.DictReader(f):
+                agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        sq = {"tag": tag, "note": "means per launch; SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_INST_* are quad-cycles "
+                                  "summed over all waves, SQ_BUSY_CYCLES is summed over the 32 shader engines",
+              "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(agg.items())}}
+        json.dump(sq, open(os.path.join(dst, tag + "_sq.json"), "w"), indent=1)
+        for k in ("k_knn2<8>", "k_fast_nms"):
+            if k in sq["kernels"]:
+                print(k, {c: round(v) for c, v in sq["kernels"][k].items()})
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ SYMBOLS = [
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
     "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
     "vo_lk_params_default", "vo_lk_track", "vo_debug_read_lk_level",
-    "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_get_stats",
+    "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_run_ex", "vo_seq_get_stats",
 ]
 
 
@@ -44,6 +44,11 @@ class PairParams(C.Structure):
     _fields_ = [("orb", OrbParams), ("ratio", C.c_float), ("max_disp", C.c_float), ("prob", C.c_double),
                 ("threshold", C.c_double), ("dist_thresh", C.c_double), ("seed", C.c_uint64),
                 ("max_iters", C.c_int32), ("cross_check", C.c_int32)]
+
+
+class SeqOutputs(C.Structure):
+    _fields_ = [("matches", C.c_void_p), ("inlier_mask", C.c_void_p), ("pose_mask", C.c_void_p),
+                ("match_cap", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PairResult(C.Structure):

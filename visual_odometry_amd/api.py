@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import OrbParams, Limits, PairParams, PairResult, LkParams
+from ._lib import OrbParams, Limits, PairParams, PairResult, LkParams, SeqOutputs
 
 KP_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -357,8 +357,10 @@ class VoSequence:
         self.L.vo_seq_get_stats(self.h, C.byref(n), C.byref(a), C.byref(b))
         return n.value, a.value, b.value
 
-    def run(self, frames, n_frames, w, h, stride, frame_stride, K, params, mem=MEM_DEVICE):
-        """frames: integer address (device or pinned host) or a uint8 numpy array (pageable host)."""
+    def run(self, frames, n_frames, w, h, stride, frame_stride, K, params, mem=MEM_DEVICE, outputs=None):
+        """frames: integer address (device or pinned host) or a uint8 numpy array (pageable host).
+        outputs: optional (matches (n-1, cap) DM_DTYPE, inlier_mask (n-1, cap) uint8, pose_mask (n-1, cap) uint8)
+        host arrays filled with the per-pair tables (any of them may be None)."""
         if isinstance(frames, np.ndarray):
             assert frames.dtype == np.uint8 and frames.flags.c_contiguous
             ptr = frames.ctypes.data_as(C.c_void_p)
@@ -366,8 +368,15 @@ class VoSequence:
             ptr = C.c_void_p(int(frames))
         K = np.ascontiguousarray(K, np.float64)
         res = (PairResult * max(n_frames - 1, 1))()
-        rc = self.L.vo_seq_run(self.h, ptr, int(mem), int(n_frames), int(w), int(h), int(stride),
-                               C.c_size_t(frame_stride), _p(K), C.byref(params), res)
+        out = None
+        if outputs is not None:
+            m, im, pm = outputs
+            cap = next(a.shape[1] for a in (m, im, pm) if a is not None)
+            for a in (m, im, pm):
+                assert a is None or (a.flags.c_contiguous and a.shape == (n_frames - 1, cap))
+            out = C.byref(SeqOutputs(_p(m), _p(im), _p(pm), cap, 0))
+        rc = self.L.vo_seq_run_ex(self.h, ptr, int(mem), int(n_frames), int(w), int(h), int(stride),
+                                  C.c_size_t(frame_stride), _p(K), C.byref(params), res, out)
         if rc != 0:
             raise VoError(rc, self.L.vo_seq_last_error(self.h).decode())
         return res

@@ -145,6 +145,8 @@ struct vo_ctx {
     // ---- vo_pairs_run_dev bookkeeping --------------------------------------------------------
     int pipe_frames = 0, pipe_ncap = 0;
     int pend_frames = 0;  // frames of the batch queued by pairs_submit and not yet collected
+    bool pend_details = false;  // that batch also brings its match / mask tables to the host
+    PinnedBuf h_dgood, h_dmask;  // GoodMatch [pair][n_cap]; uint8 [2][pair][n_cap] (inlier mask, pose mask)
     double pend_K[9];
     vo_pair_params pend_prm;
     std::vector<int> pipe_nkp;
@@ -206,8 +208,8 @@ int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, s
 
 // device-resident batch (vo_pipeline.cpp): queue everything / wait and fill the results
 int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
-                 const double* K, const vo_pair_params* prm);
-int pairs_collect(vo_ctx* c, vo_pair_result* results);
+                 const double* K, const vo_pair_params* prm, bool details);
+int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out, size_t pair0);
 
 // profiling bracket (no-ops unless vo_prof_enable(ctx, 1))
 struct ProfScope {

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_match_filter(FilterArgs a) {
     for (int q0 = 0; q0 < nq; q0 += 1024) {
         const int qi = q0 + threadIdx.x;
         bool keep = false;
-        GoodMatch gm = {0, 0, 0, 0};
+        GoodMatch gm = {0, 0, 0, 0.f};
         float2 a0 = make_float2(0.f, 0.f), a1 = a0;
         if (qi < nq) {
             const uint2 k = knn[qi];
@@ -315,9 +315,9 @@ __global__ __launch_bounds__(1024) void k_match_filter(FilterArgs a) {
                     const double nrm = sqrt((double)dx * (double)dx + (double)dy * (double)dy);
                     if (mutual && nrm < (double)a.max_disp) {
                         keep = true;
-                        gm.q = qi;
-                        gm.t = ti;
-                        gm.dist = (int)(k.x >> VO_KEY_SHIFT);
+                        gm.queryIdx = qi;
+                        gm.trainIdx = ti;
+                        gm.distance = d0;
                     }
                 }
             }

@@ -179,9 +179,7 @@ int knn_static_init(int device);  // address of this device's static matcher wor
 void launch_knn2(hipStream_t st, const KnnArgs& a);
 void launch_knn2_merge(hipStream_t st, const KnnArgs& a);  // no-op unless splits > 1
 
-struct GoodMatch {
-    int q, t, dist, pad;
-};
+typedef vo_dmatch GoodMatch;  // filtered matches leave the device in cv::DMatch layout
 struct FilterArgs {
     const uint2* knn;          // [pair][nq_cap]
     const uint2* rev;          // [pair][nq_cap] nearest queries of the train rows, or nullptr: no cross-check

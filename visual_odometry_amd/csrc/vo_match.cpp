@@ -197,13 +197,7 @@ static int filter_host(vo_ctx* c, const vo_dmatch* knn, const int* n_valid, int 
     VO_HIP(c, hipMemcpyAsync(c->h_good.p, c->d_good.p, (size_t)nq * sizeof(GoodMatch), hipMemcpyDeviceToHost,
                              c->stream));
     VO_TRY(vo_xfer_finish(c));
-    const GoodMatch* g = c->h_good.as<GoodMatch>();
-    for (int i = 0; i < *h_n; i++) {
-        good[i].queryIdx = g[i].q;
-        good[i].trainIdx = g[i].t;
-        good[i].imgIdx = 0;
-        good[i].distance = (float)g[i].dist;
-    }
+    memcpy(good, c->h_good.p, (size_t)*h_n * sizeof(GoodMatch));
     *n_good = *h_n;
     return VO_OK;
 }

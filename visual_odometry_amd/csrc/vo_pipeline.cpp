@@ -61,6 +61,16 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
     launch_pack_results(c->stream, pa, at, c->d_pack.as<uint32_t>());
     VO_TRY(vo_check_launch(c, "result gather"));
     VO_HIP(c, hipMemcpyAsync(c->h_pack.p, c->d_pack.p, (size_t)at * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->pend_details) {
+        // the per-pair tables the reference's matcher() / updatePose() hand back (MatchesInfo::matches,
+        // inliers_mask, recoverPose's mask), fixed stride n_cap; pairs_collect copies the used rows out
+        const size_t rows = (size_t)npairs * n_cap;
+        VO_TRY(vo_ensure_pinned(c, c->h_dgood, rows * sizeof(GoodMatch)));
+        VO_TRY(vo_ensure_pinned(c, c->h_dmask, 2 * rows));
+        VO_HIP(c, hipMemcpyAsync(c->h_dgood.p, c->d_good.p, rows * sizeof(GoodMatch), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpyAsync(c->h_dmask.p, c->d_mask.p, rows, hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpyAsync(c->h_dmask.as<uint8_t>() + rows, c->d_pmask.p, rows, hipMemcpyDeviceToHost, c->stream));
+    }
     c->pipe_ncap = n_cap;
     return VO_OK;
 }
@@ -74,7 +84,7 @@ static void pairs_unpack(vo_ctx* c) {
 // Queue the whole batch on the context's stream without a host round trip: ORB with the
 // device-side keypoint selection, matching, essential matrix, pose, result copies.
 int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
-                 const double* K, const vo_pair_params* prm) {
+                 const double* K, const vo_pair_params* prm, bool details) {
     if (!d_frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
         !prm)
         return c->fail(VO_ERR_INVALID, "vo_pairs_run_dev: bad argument");
@@ -84,6 +94,7 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
     VO_HIP(c, hipSetDevice(c->device));
     c->pipe_frames = 0;
     c->pend_frames = 0;
+    c->pend_details = details;
     VO_TRY(feat_setup(c, w, h, &prm->orb, n_frames));
     const int n_bound = feat_n_bound(c, prm->orb.nfeatures);
     {
@@ -100,8 +111,9 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
     return VO_OK;
 }
 
-// Wait for the batch queued by pairs_submit and fill results[n_frames - 1].
-int pairs_collect(vo_ctx* c, vo_pair_result* results) {
+// Wait for the batch queued by pairs_submit and fill results[n_frames - 1]; with `out`, also the matches and
+// masks of pair p of the batch into row pair0 + p of the caller's tables.
+int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out, size_t pair0) {
     const int n_frames = c->pend_frames;
     if (n_frames < 2 || !results) return c->fail(VO_ERR_INVALID, "no batch is pending");
     VO_HIP(c, hipSetDevice(c->device));
@@ -145,6 +157,19 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results) {
         }
     }
     c->pipe_frames = n_frames;
+    if (out && c->pend_details) {
+        const size_t n_cap = (size_t)c->pipe_ncap, rows = (size_t)npairs * n_cap;
+        const size_t cap = (size_t)out->match_cap;
+        for (int p = 0; p < npairs; p++) {
+            const size_t cnt = (size_t)ng[p];
+            if (cnt > cap)
+                return c->fail(VO_ERR_CAPACITY, "pair %zu has %zu matches, match_cap is %zu", pair0 + p, cnt, cap);
+            const size_t at = (pair0 + p) * cap;
+            if (out->matches) memcpy(out->matches + at, c->h_dgood.as<GoodMatch>() + p * n_cap, cnt * sizeof(GoodMatch));
+            if (out->inlier_mask) memcpy(out->inlier_mask + at, c->h_dmask.as<uint8_t>() + p * n_cap, cnt);
+            if (out->pose_mask) memcpy(out->pose_mask + at, c->h_dmask.as<uint8_t>() + rows + p * n_cap, cnt);
+        }
+    }
     return VO_OK;
 }
 
@@ -193,8 +218,8 @@ int vo_pairs_run_dev(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, in
                      size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results) {
     if (!c) return VO_ERR_INVALID;
     if (!results) return c->fail(VO_ERR_INVALID, "vo_pairs_run_dev: bad argument");
-    VO_TRY(pairs_submit(c, d_frames, n_frames, w, h, stride, frame_stride, K, prm));
-    return pairs_collect(c, results);
+    VO_TRY(pairs_submit(c, d_frames, n_frames, w, h, stride, frame_stride, K, prm, false));
+    return pairs_collect(c, results, nullptr, 0);
 }
 
 int vo_seq_create(int device, const vo_limits* limits, int n_streams, int pairs_per_chunk, vo_seq** out) {
@@ -260,7 +285,15 @@ vo_ctx* vo_seq_ctx(vo_seq* s, int i) { return (s && i >= 0 && i < (int)s->ctx.si
 
 int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
                size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results) {
+    return vo_seq_run_ex(s, frames, mem, n_frames, w, h, stride, frame_stride, K, prm, results, nullptr);
+}
+
+int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
+                  size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results,
+                  const vo_seq_outputs* out) {
     if (!s) return VO_ERR_INVALID;
+    if (out && (out->match_cap <= 0 || (!out->matches && !out->inlier_mask && !out->pose_mask))) out = nullptr;
+    const bool details = out != nullptr;
     if (!frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
         !prm || !results || (mem != VO_MEM_HOST && mem != VO_MEM_DEVICE && mem != VO_MEM_HOST_PINNED))
         return s->fail(VO_ERR_INVALID, "vo_seq_run: bad argument");
@@ -279,7 +312,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
     for (auto& P : s->pre) P.chunk[0] = P.chunk[1] = -1;  // nothing of this run is on the device yet
     auto collect = [&](int k) {
         const auto t0 = clk::now();
-        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], results + (size_t)k * B));
+        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], results + (size_t)k * B, out, (size_t)k * B));
         s->wait_ms += ms_since(t0);
         return r;
     };
@@ -300,7 +333,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
             ~Acc() { s->submit_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
         } acc{s, t_submit};
         if (mem == VO_MEM_DEVICE) {
-            rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm));
+            rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm, details));
             continue;
         }
         if (mem == VO_MEM_HOST_PINNED && stride == w && frame_stride == img) {
@@ -336,7 +369,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
                 rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(pe));
                 break;
             }
-            rc = s->from(c, pairs_submit(c, static_cast<const uint8_t*>(P.img[b]), nf, w, h, w, img, K, prm));
+            rc = s->from(c, pairs_submit(c, static_cast<const uint8_t*>(P.img[b]), nf, w, h, w, img, K, prm, details));
             // the other buffer held chunk k - S, which has been collected: send chunk k + S into it now
             if (rc == VO_OK && k + S < nchunks && upload(k + S, b ^ 1) != hipSuccess)
                 rc = s->fail(VO_ERR_DEVICE, "frame prefetch failed");
@@ -364,7 +397,7 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
             rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(e));
             break;
         }
-        rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm));
+        rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm, details));
     }
     if (rc != VO_OK)
         for (auto& P : s->pre)
@@ -410,9 +443,8 @@ int vo_pairs_get_matches(vo_ctx* c, int pair, vo_dmatch* good, uint8_t* inlier_m
     *n = cnt;
     if (cnt > cap) return c->fail(VO_ERR_CAPACITY, "vo_pairs_get_matches: %d matches, capacity %d", cnt, cap);
     if (cnt == 0) return VO_OK;
-    std::vector<GoodMatch> tmp(cnt);
     if (good)
-        VO_HIP(c, hipMemcpyAsync(tmp.data(), c->d_good.as<GoodMatch>() + pair * n_cap, (size_t)cnt * sizeof(GoodMatch),
+        VO_HIP(c, hipMemcpyAsync(good, c->d_good.as<GoodMatch>() + pair * n_cap, (size_t)cnt * sizeof(GoodMatch),
                                  hipMemcpyDeviceToHost, c->stream));
     if (inlier_mask)
         VO_HIP(c, hipMemcpyAsync(inlier_mask, c->d_mask.as<uint8_t>() + pair * n_cap, cnt, hipMemcpyDeviceToHost,
@@ -421,13 +453,6 @@ int vo_pairs_get_matches(vo_ctx* c, int pair, vo_dmatch* good, uint8_t* inlier_m
         VO_HIP(c, hipMemcpyAsync(pose_mask, c->d_pmask.as<uint8_t>() + pair * n_cap, cnt, hipMemcpyDeviceToHost,
                                  c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    if (good)
-        for (int i = 0; i < cnt; i++) {
-            good[i].queryIdx = tmp[i].q;
-            good[i].trainIdx = tmp[i].t;
-            good[i].imgIdx = 0;
-            good[i].distance = (float)tmp[i].dist;
-        }
     return VO_OK;
 }
 
