@@ -117,3 +117,82 @@ def test_seq_bad_arguments(seq_frames):
     with pytest.raises(api.VoError):
         seq.run(np.ascontiguousarray(fr), 4, W, H, W, W * H, KS, api.pair_params(500), mem=7)
     seq.close()
+
+
+def _oracle_pair(oracle, f0, f1, nfeatures, Kc):
+    po = oracle.orb_params(nfeatures)
+    k0, d0 = oracle.orb_detect_compute(f0, po)
+    k1, d1 = oracle.orb_detect_compute(f1, po)
+    knn, nv = oracle.knn2_hamming(d0, d1)
+    good = oracle.match_filter(knn, nv, k0, k1, 0.7, 200.0)
+    p0 = np.stack([k0["x"][good["queryIdx"]], k0["y"][good["queryIdx"]]], 1)
+    p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
+    rc, E, mask, _ = oracle.find_essential(p0, p1, Kc, oracle.RANSAC)
+    ng, R, t, pm, _ = oracle.recover_pose(E, p0, p1, Kc, 200.0, mask)
+    return dict(nk0=len(k0), nk1=len(k1), good=good, rc=rc, E=E, mask=mask, ng=ng, R=R, t=t, pm=pm)
+
+
+def test_seq_outputs_equal_get_matches(seq_frames):
+    """vo_seq_run_ex's match / mask tables are what vo_pairs_get_matches returns for the same frames."""
+    fr, _ = seq_frames
+    n = fr.shape[0]
+    d = torch.from_numpy(fr).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx = api.VoContext(0)
+    ctx.pairs_run_dev(d.data_ptr(), n, W, H, W, W * H, KS, api.pair_params(500))
+    want = [ctx.pairs_get_matches(p) for p in range(n - 1)]
+    ctx.close()
+    cap = 700
+    m = np.zeros((n - 1, cap), api.DM_DTYPE)
+    im = np.full((n - 1, cap), 9, np.uint8)
+    pm = np.full((n - 1, cap), 9, np.uint8)
+    seq = api.VoSequence(0, n_streams=3, pairs_per_chunk=4)
+    res = seq.run(d.data_ptr(), n, W, H, W, W * H, KS, api.pair_params(500), outputs=(m, im, pm))
+    for p in range(n - 1):
+        g, a, b = want[p]
+        k = res[p].n_good
+        assert k == len(g) and np.array_equal(m[p, :k], g) and np.array_equal(im[p, :k], a) and np.array_equal(pm[p, :k], b)
+        assert (im[p, k:] == 9).all()  # rows beyond n_good are left alone
+    with pytest.raises(api.VoError) as e:  # a table too narrow for a pair's matches
+        seq.run(d.data_ptr(), n, W, H, W, W * H, KS, api.pair_params(500), outputs=(m[:, :8].copy(), None, None))
+    assert e.value.code == api.VO_ERR_CAPACITY
+    seq.close()
+
+
+def test_seq_full_length_sequence_configs3(oracle):
+    """BASELINE.json configs[3] at its stated size: one seq-00-shaped sequence of 4541 frames (1241 x 376, 2k
+    ORB) through vo_seq_run_ex in chunks of 48 pairs on 3 streams, the way bench.py runs it (the sequence is
+    cut back and forth from 97 rendered frames).  Every pair must report a pose; the first chunk, the last
+    chunk's last pair, a mid-sequence pair and a pair that straddles two chunks are checked against the
+    oracle: matches bit-exact, masks bit-exact, E / R / t within north_star's 1e-6."""
+    n, base = 4541, 97
+    fr, _, Kc = synth.make_sequence(11, base, workers=8)
+    idx = synth.pingpong_indices(base, n)
+    d = torch.from_numpy(fr).to("cuda:0").index_select(0, torch.from_numpy(idx).to("cuda:0"))
+    torch.cuda.synchronize()
+    cap = 2314
+    m = np.zeros((n - 1, cap), api.DM_DTYPE)
+    im = np.zeros((n - 1, cap), np.uint8)
+    pm = np.zeros((n - 1, cap), np.uint8)
+    seq = api.VoSequence(0, n_streams=3, pairs_per_chunk=48)
+    res = seq.run(d.data_ptr(), n, 1241, 376, 1241, 1241 * 376, Kc, api.pair_params(2000), outputs=(m, im, pm))
+    assert seq.stats()[0] == 95
+    seq.close()
+    assert all(res[p].status == 0 for p in range(n - 1))
+    assert all(res[p].n_kp0 >= 2000 and res[p].n_good > 100 and res[p].n_pose > 50 for p in range(n - 1))
+    # pairs p and p' over the same two base frames in the same order give identical results wherever they sit
+    period = 2 * (base - 1)
+    for p in (0, 5, 47, 48, 100):
+        a, b = res[p], res[p + 10 * period]
+        assert (a.n_good, a.n_inliers, a.n_pose, tuple(a.E)) == (b.n_good, b.n_inliers, b.n_pose, tuple(b.E))
+    for p in (0, 1, 47, 48, 2270, n - 2):  # 47 | 48: the frame two chunks share
+        o = _oracle_pair(oracle, fr[idx[p]], fr[idx[p + 1]], 2000, Kc)
+        r = res[p]
+        k = r.n_good
+        assert (r.n_kp0, r.n_kp1, k, r.status) == (o["nk0"], o["nk1"], len(o["good"]), o["rc"])
+        assert np.array_equal(m[p, :k], o["good"])
+        assert np.array_equal(im[p, :k], o["mask"]) and r.n_inliers == int(o["mask"].sum())
+        assert np.array_equal(pm[p, :k], o["pm"]) and r.n_pose == o["ng"]
+        Eg = np.array(r.E).reshape(3, 3)
+        assert min(np.abs(Eg - o["E"]).max(), np.abs(Eg + o["E"]).max()) < 1e-6
+        assert np.abs(np.array(r.R).reshape(3, 3) - o["R"]).max() < 1e-6 and np.abs(np.array(r.t) - o["t"]).max() < 1e-6

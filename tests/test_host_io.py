@@ -72,12 +72,32 @@ def test_remove_points_equals_oracle(oracle, seed):
 
 
 def test_kitti_metric_on_known_drift():
-    # straight line, 1 m per frame; the estimate is scaled by 1.02 -> 2 % translation error, no rotation error
+    # straight line, 1 m per frame; the estimate is scaled by 1.02 -> 2 % of the distance actually covered, no
+    # rotation error.  A sub-sequence ends at the first frame whose distance is strictly greater than
+    # start + length (the devkit's rule: reference src/kitti/evaluate_odometry.cpp, lastFrameFromSegmentLength),
+    # so with exact hits at 1 m spacing it covers length + 1 metres.
     n = 1000
     gt = np.tile(np.eye(3, 4), (n, 1, 1))
     gt[:, 2, 3] = np.arange(n)
     res = gt.copy()
     res[:, 2, 3] *= 1.02
     t, r, cnt = host_api.kitti_sequence_errors(gt, res)
-    assert abs(t - 0.02) < 1e-9 and r < 1e-7 and cnt > 100
+    want, k = 0.0, 0
+    for first in range(0, n, 10):
+        for L in (100, 200, 300, 400, 500, 600, 700, 800):
+            last = next((i for i in range(first, n) if gt[i, 2, 3] > gt[first, 2, 3] + L), -1)
+            if last < 0:
+                continue
+            assert last - first == L + 1
+            want += 0.02 * (L + 1) / L
+            k += 1
+    assert cnt == k and abs(t - want / k) < 1e-9 and r < 1e-7
     assert host_api.kitti_sequence_errors(gt[:50], res[:50]) is None  # shorter than 100 m
+
+
+def test_load_poses_tolerates_blank_lines_and_stops_at_garbage(tmp_path):
+    p = tmp_path / "p.txt"
+    rows = [" ".join(str(float(i * 12 + j)) for j in range(12)) for i in range(3)]
+    p.write_text(rows[0] + "\n\n" + rows[1] + "\n" + "1 2 3\n" + rows[2] + "\n")
+    got = host_api.load_poses(str(p))
+    assert got.shape == (2, 3, 4) and got[1, 2, 3] == 23.0

@@ -235,3 +235,28 @@ def test_synthetic_kitti_layout_roundtrip(tmp_path, oracle):
 
     im = np.array(Image.open(tmp_path / "sequences" / "01" / "image_0" / "000001.png"))
     assert np.array_equal(im, fr[1])
+
+
+def test_orb_pattern_table_is_frozen_and_shared():
+    """The 256 x 4 rBRIEF test pattern (cv's bit_pattern_31_) is data re-typed from memory, the one thing a
+    typo in which no parity test can see (the oracle and the kernels read the same numbers).  Two separate
+    recitations of the table (round 1, round 2) agree on all 1024 numbers; this test freezes that state and
+    the properties the published table has."""
+    import hashlib
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tables = []
+    for rel in ("oracle/orb_pattern.inc", "visual_odometry_amd/csrc/orb_pattern.inc"):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, rel)).read(), flags=re.S)
+        tables.append([int(v) for v in re.findall(r"-?\d+", src)])
+    assert tables[0] == tables[1] and len(tables[0]) == 1024
+    t = np.array(tables[0]).reshape(256, 4)
+    assert hashlib.sha256(bytes(int(v) & 255 for v in tables[0])).hexdigest() == \
+        "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+    assert t.min() == -13 and t.max() == 12                      # the learning stage sampled a 26 x 26 grid
+    assert (np.hypot(t[:, 0], t[:, 1]).max() < 18.5) and (np.hypot(t[:, 2], t[:, 3]).max() < 18.5)
+    assert not np.any((t[:, 0] == t[:, 2]) & (t[:, 1] == t[:, 3]))  # no test compares a pixel with itself
+    assert len({tuple(r) for r in t.tolist()}) == 256            # 256 distinct tests
+    assert list(t[0]) == [8, -3, 9, 5] and list(t[255]) == [-1, -6, 0, -11]

@@ -542,17 +542,22 @@ vo::Matd kittiResultMat(const vo::Matd& pose) {
     return m;
 }
 
+// Ground-truth / result trajectories: text, one pose per line, the first three rows of the 4 x 4
+// camera-to-world matrix row-major (README.md:54-94 of the reference describes the layout).  Lines that do
+// not hold twelve numbers end the file (a trailing blank line is fine).
 std::vector<vo::Matd> loadPoses(const std::string& file_name) {
     std::vector<vo::Matd> poses;
-    FILE* fp = fopen(file_name.c_str(), "r");
-    if (!fp) return poses;
-    while (!feof(fp)) {
+    std::ifstream in(file_name);
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream fields(line);
         vo::Matd P = vo::Matd::eye(4, 4);
-        if (fscanf(fp, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", &P(0, 0), &P(0, 1), &P(0, 2), &P(0, 3),
-                   &P(1, 0), &P(1, 1), &P(1, 2), &P(1, 3), &P(2, 0), &P(2, 1), &P(2, 2), &P(2, 3)) == 12)
-            poses.push_back(P);
+        int got = 0;
+        for (double v; got < 12 && (fields >> v); got++) P(got / 4, got % 4) = v;
+        if (got == 0 && line.find_first_not_of(" \t\r") == std::string::npos) continue;  // blank line
+        if (got != 12) break;
+        poses.push_back(P);
     }
-    fclose(fp);
     return poses;
 }
 

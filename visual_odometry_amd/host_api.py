@@ -140,7 +140,7 @@ def kitti_sequence_errors(gt, res, step=10, lengths=KITTI_LENGTHS):
     t_err, r_err = [], []
     for first in range(0, n, step):
         for L in lengths:
-            last = np.searchsorted(dist, dist[first] + L)
+            last = np.searchsorted(dist, dist[first] + L, side="right")  # first frame strictly beyond the length
             if last >= n:
                 continue
             dgt = np.linalg.inv(gt[first]) @ gt[last]
