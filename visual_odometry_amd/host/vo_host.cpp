@@ -9,6 +9,11 @@
 #include <cstring>
 #include <random>
 
+#include <map>
+#include <set>
+#include <unordered_map>
+
+#include "bundle_adjustment.h"
 #include "feature_detector.h"
 #include "matcher.h"
 #include "vo_pose.h"
@@ -217,26 +222,135 @@ std::vector<vo::MatchesInfo> matcher(const std::vector<vo::ImageFeatures>& featu
     return pairwise_matches;
 }
 
+// Feature tracks across the window (reference: src/matcher/matcher.cpp:55-86).  The reference's rule, kept
+// exactly: an inlier match (q in image a, t in image b) joins the FIRST track, in creation order, whose
+// entry for a is q or whose entry for b is t, overwriting both entries; otherwise it starts a track.
+// The reference finds that track by scanning all of them (O(matches x tracks)); here every (image, keypoint)
+// value keeps the ordered set of tracks that currently hold it, so the first one is a lookup, and an
+// overwrite moves the track between sets.  (A plain union-find would not do: overwriting can leave two
+// tracks holding the same keypoint, and can drop a keypoint from a track.)
 std::vector<std::vector<int>> createMatchMatrix(const std::vector<vo::MatchesInfo> pairwise_matches,
                                                 const int pose_count) {
     std::vector<std::vector<int>> tracks;
+    std::vector<std::unordered_map<int, std::set<int>>> holders((size_t)std::max(pose_count, 0));
+    auto first_holder = [&](int img, int kp) {
+        const auto it = holders[img].find(kp);
+        return it == holders[img].end() || it->second.empty() ? -1 : *it->second.begin();
+    };
+    auto set_entry = [&](int row, int img, int kp) {
+        int& cell = tracks[row][img];
+        if (cell == kp) return;
+        if (cell != -1) {
+            auto it = holders[img].find(cell);
+            it->second.erase(row);
+            if (it->second.empty()) holders[img].erase(it);
+        }
+        cell = kp;
+        holders[img][kp].insert(row);
+    };
     for (const auto& pw : pairwise_matches) {
         const int a = pw.src_img_idx, b = pw.dst_img_idx;
+        if (a < 0 || b < 0 || a >= pose_count || b >= pose_count)
+            throw vo::Error(VO_ERR_INVALID, "createMatchMatrix: image index outside pose_count");
         for (size_t i = 0; i < pw.matches.size(); i++) {
             if (pw.inliers_mask[i] != 1) continue;
             const int q = pw.matches[i].queryIdx, t = pw.matches[i].trainIdx;
-            // the first track (in creation order) that already holds either end takes both
-            auto it = std::find_if(tracks.begin(), tracks.end(),
-                                   [&](const std::vector<int>& r) { return r[a] == q || r[b] == t; });
-            if (it == tracks.end()) {
+            const int ra = first_holder(a, q), rb = first_holder(b, t);
+            int row = ra < 0 ? rb : (rb < 0 ? ra : std::min(ra, rb));
+            if (row < 0) {
                 tracks.emplace_back(pose_count, -1);
-                it = tracks.end() - 1;
+                row = (int)tracks.size() - 1;
             }
-            (*it)[a] = q;
-            (*it)[b] = t;
+            set_entry(row, a, q);
+            set_entry(row, b, t);
         }
     }
     return tracks;
+}
+
+// ---- bundle adjustment front end (bundle_adjustment.h) ---------------------------------------------
+void BundleAdjustment::init(const vo::Matd& K, size_t max_frames) {
+    K_ = K;
+    max_frames_ = max_frames;
+    count_ = 0;
+    features_.clear();
+    R_.clear();
+    t_.clear();
+    pairwise_matches_.clear();
+    match_matrix_.clear();
+    points_3d_.clear();
+    cameras_visible_.clear();
+    points_img_.clear();
+}
+
+void BundleAdjustment::addKeyFrame(const VOFrame& frame) {
+    R_.push_back(frame.pose_R);
+    t_.push_back(frame.pose_t);
+    vo::ImageFeatures f;
+    feature_detector_.detectComputeORB(frame, &f.keypoints, &f.descriptors);  // the reference: AKAZE (see header)
+    f.img_idx = count_++;
+    f.img_size.width = frame.image.width;
+    f.img_size.height = frame.image.height;
+    features_.push_back(std::move(f));
+    if (features_.size() > max_frames_) {
+        features_.erase(features_.begin());
+        R_.erase(R_.begin());
+        t_.erase(t_.begin());
+    }
+    pairwise_matches_ = matcher(features_, K_);
+    match_matrix_ = createMatchMatrix(pairwise_matches_, (int)R_.size());
+    setPBAPoints();
+}
+
+void BundleAdjustment::setPBAPoints() {
+    points_3d_.clear();
+    cameras_visible_.clear();
+    points_img_.clear();
+    struct Track {
+        std::vector<int> cams;
+        std::vector<vo::Point2f> points;
+    };
+    // tracks with at least three views, grouped by the two key frames they are triangulated from so that
+    // each group is one vo_triangulate call
+    std::vector<Track> tracks;
+    std::map<std::pair<int, int>, std::vector<int>> groups;
+    for (const auto& row : match_matrix_) {
+        Track tr;
+        for (int cam = 0; cam < (int)row.size(); cam++) {
+            if (row[cam] == -1) continue;
+            tr.cams.push_back(cam);
+            tr.points.push_back(features_[cam].keypoints[row[cam]].pt);
+        }
+        if (tr.points.size() < 3) continue;
+        groups[{tr.cams[0], tr.cams[1]}].push_back((int)tracks.size());
+        tracks.push_back(std::move(tr));
+    }
+    std::vector<vo::Point3d> tri(tracks.size());
+    for (const auto& g : groups) {
+        const int c0 = g.first.first, c1 = g.first.second;
+        std::vector<vo::Point2f> p0, p1;
+        for (int i : g.second) {
+            p0.push_back(tracks[i].points[0]);
+            p1.push_back(tracks[i].points[1]);
+        }
+        const std::vector<vo::Point3d> x = triangulate(p0, p1, getProjectionMatrix(K_, vo::hconcat(R_[c0], t_[c0])),
+                                                       getProjectionMatrix(K_, vo::hconcat(R_[c1], t_[c1])));
+        for (size_t k = 0; k < g.second.size(); k++) tri[g.second[k]] = x[k];
+    }
+    for (size_t i = 0; i < tracks.size(); i++) {
+        // the point in the first view's frame: R^T (X - t)
+        const vo::Matd& R = R_[tracks[i].cams[0]];
+        const vo::Matd& t = t_[tracks[i].cams[0]];
+        const double d[3] = {tri[i].x - t(0, 0), tri[i].y - t(1, 0), tri[i].z - t(2, 0)};
+        double o[3];
+        for (int c = 0; c < 3; c++) o[c] = R(0, c) * d[0] + R(1, c) * d[1] + R(2, c) * d[2];
+        const double dist = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+        if (dist < kMax3DDist && o[2] > kMin3DDist && std::fabs(o[0]) < kMax3DWidth) {
+            points_3d_.push_back(tri[i]);
+            cameras_visible_.push_back(tracks[i].cams);
+            points_img_.push_back(tracks[i].points);
+        }
+    }
 }
 
 // ---- triangulation ------------------------------------------------------------------------------
@@ -709,6 +823,135 @@ int vo_host_remove_points(float* p0, float* p1, int n, uint8_t* status, double* 
     if (*n3d_out) memcpy(pts3d, a.points_3d.data(), a.points_3d.size() * 24);
     *nmask_out = (int)a.mask.d.size();
     if (*nmask_out) memcpy(mask, a.mask.d.data(), a.mask.d.size());
+    return 0;
+}
+
+// ---- feature tracks and the bundle-adjustment front end -------------------------------------------------
+int vo_host_create_match_matrix(const int* src, const int* dst, const int* off, int n_pairs, const int* q,
+                                const int* t, const uint8_t* inliers, int pose_count, int* out, int cap_rows,
+                                int* n_rows) {
+    try {
+        std::vector<vo::MatchesInfo> pw((size_t)n_pairs);
+        for (int p = 0; p < n_pairs; p++) {
+            pw[p].src_img_idx = src[p];
+            pw[p].dst_img_idx = dst[p];
+            for (int i = off[p]; i < off[p + 1]; i++) {
+                vo::DMatch m;
+                m.queryIdx = q[i];
+                m.trainIdx = t[i];
+                pw[p].matches.push_back(m);
+                pw[p].inliers_mask.push_back(inliers[i]);
+            }
+        }
+        const auto mm = createMatchMatrix(pw, pose_count);
+        *n_rows = (int)mm.size();
+        for (int r = 0; r < (int)mm.size() && r < cap_rows; r++)
+            for (int c = 0; c < pose_count; c++) out[(size_t)r * pose_count + c] = mm[r][c];
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+struct vo_host_ba {
+    BundleAdjustment* ba = nullptr;
+};
+
+vo_host_ba* vo_host_ba_create(const double* K, int max_frames, int nfeatures, char* err, int err_cap) {
+    try {
+        vo_host_ba* b = new vo_host_ba();
+        b->ba = new BundleAdjustment(nfeatures);
+        vo::Matd Km(3, 3);
+        for (int i = 0; i < 9; i++) Km.d[i] = K[i];
+        b->ba->init(Km, (size_t)max_frames);
+        return b;
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return nullptr;
+    }
+}
+
+void vo_host_ba_destroy(vo_host_ba* b) {
+    if (!b) return;
+    delete b->ba;
+    delete b;
+}
+
+int vo_host_ba_add_key_frame(vo_host_ba* b, const uint8_t* gray, int w, int h, const double* pose_R,
+                             const double* pose_t, char* err, int err_cap) {
+    try {
+        VOFrame f;
+        vo::Image im;
+        im.width = w;
+        im.height = h;
+        im.px.assign(gray, gray + (size_t)w * h);
+        f.setImage(std::move(im));
+        f.pose_R = vo::Matd(3, 3);
+        f.pose_t = vo::Matd(3, 1);
+        for (int i = 0; i < 9; i++) f.pose_R.d[i] = pose_R[i];
+        for (int i = 0; i < 3; i++) f.pose_t.d[i] = pose_t[i];
+        b->ba->addKeyFrame(f);
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return -1;
+    }
+}
+
+int vo_host_ba_counts(vo_host_ba* b, int* n_frames, int* n_pairs, int* n_rows, int* n_points) {
+    *n_frames = (int)b->ba->features().size();
+    *n_pairs = (int)b->ba->pairwiseMatches().size();
+    *n_rows = (int)b->ba->matchMatrix().size();
+    *n_points = (int)b->ba->points3D().size();
+    return 0;
+}
+
+int vo_host_ba_features(vo_host_ba* b, int frame, vo_keypoint* kp, uint8_t* desc, int cap, int* n) {
+    const auto& f = b->ba->features()[(size_t)frame];
+    *n = (int)f.keypoints.size();
+    if (*n > cap) return -1;
+    if (kp) memcpy(kp, f.keypoints.data(), (size_t)*n * sizeof(vo_keypoint));
+    if (desc) memcpy(desc, f.descriptors.d.data(), (size_t)*n * 32);
+    return 0;
+}
+
+int vo_host_ba_pair(vo_host_ba* b, int pair, int* src, int* dst, vo_dmatch* matches, uint8_t* inliers, int cap,
+                    int* n) {
+    const auto& pw = b->ba->pairwiseMatches()[(size_t)pair];
+    *src = pw.src_img_idx;
+    *dst = pw.dst_img_idx;
+    *n = (int)pw.matches.size();
+    if (*n > cap) return -1;
+    if (matches) memcpy(matches, pw.matches.data(), (size_t)*n * sizeof(vo_dmatch));
+    if (inliers) memcpy(inliers, pw.inliers_mask.data(), (size_t)*n);
+    return 0;
+}
+
+int vo_host_ba_match_matrix(vo_host_ba* b, int* out) {
+    const auto& mm = b->ba->matchMatrix();
+    const size_t nf = b->ba->features().size();
+    for (size_t r = 0; r < mm.size(); r++)
+        for (size_t c = 0; c < nf; c++) out[r * nf + c] = mm[r][c];
+    return 0;
+}
+
+// points: n x 3; visible: n x n_frames (1 where the key frame sees the point); img_pts: n x n_frames x 2
+int vo_host_ba_points(vo_host_ba* b, double* points, uint8_t* visible, float* img_pts) {
+    const size_t nf = b->ba->features().size();
+    const auto& P = b->ba->points3D();
+    for (size_t i = 0; i < P.size(); i++) {
+        points[3 * i] = P[i].x;
+        points[3 * i + 1] = P[i].y;
+        points[3 * i + 2] = P[i].z;
+        const auto& cams = b->ba->camerasVisible()[i];
+        const auto& pts = b->ba->pointsImg()[i];
+        for (size_t c = 0; c < nf; c++) visible[i * nf + c] = 0;
+        for (size_t k = 0; k < cams.size(); k++) {
+            visible[i * nf + cams[k]] = 1;
+            img_pts[(i * nf + cams[k]) * 2] = pts[k].x;
+            img_pts[(i * nf + cams[k]) * 2 + 1] = pts[k].y;
+        }
+    }
     return 0;
 }
 

@@ -6,6 +6,8 @@
 
 #include <stdint.h>
 
+#include "../../include/vo_types.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,6 +38,28 @@ int vo_host_save_poses(const char* file_name, const double* poses, int n);
 /* removePoints through the mirror (same argument meaning as the oracle's restatement). */
 int vo_host_remove_points(float* p0, float* p1, int n, uint8_t* status, double* pts3d, int n3d, uint8_t* mask,
                           int nmask, int* n_out, int* n3d_out, int* nmask_out, int* ret);
+
+/* createMatchMatrix through the mirror (reference: src/matcher/matcher.cpp:55-86).  Pair p joins images
+ * src[p] -> dst[p] with the matches off[p] .. off[p+1]-1 of q[] / t[] / inliers[].  out: cap_rows x pose_count,
+ * -1 where a track has no keypoint; *n_rows is the true row count. */
+int vo_host_create_match_matrix(const int* src, const int* dst, const int* off, int n_pairs, const int* q,
+                                const int* t, const uint8_t* inliers, int pose_count, int* out, int cap_rows,
+                                int* n_rows);
+
+/* BundleAdjustment front end of the mirror (bundle_adjustment.h): init, addKeyFrame, and what
+ * setPBAPoints() leaves for an optimiser.  pose_R 3x3 / pose_t 3: camera-to-world pose of the key frame. */
+typedef struct vo_host_ba vo_host_ba;
+vo_host_ba* vo_host_ba_create(const double* K, int max_frames, int nfeatures, char* err, int err_cap);
+void vo_host_ba_destroy(vo_host_ba* b);
+int vo_host_ba_add_key_frame(vo_host_ba* b, const uint8_t* gray, int w, int h, const double* pose_R,
+                             const double* pose_t, char* err, int err_cap);
+int vo_host_ba_counts(vo_host_ba* b, int* n_frames, int* n_pairs, int* n_rows, int* n_points);
+int vo_host_ba_features(vo_host_ba* b, int frame, vo_keypoint* kp, uint8_t* desc, int cap, int* n);
+int vo_host_ba_pair(vo_host_ba* b, int pair, int* src, int* dst, vo_dmatch* matches, uint8_t* inliers, int cap,
+                    int* n);
+int vo_host_ba_match_matrix(vo_host_ba* b, int* out /* n_rows x n_frames */);
+int vo_host_ba_points(vo_host_ba* b, double* points /* n x 3 */, uint8_t* visible /* n x n_frames */,
+                      float* img_pts /* n x n_frames x 2 */);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvo_host.so")
 SYMBOLS = ["vo_host_vo_create", "vo_host_vo_destroy", "vo_host_vo_add_image", "vo_host_vo_state",
            "vo_host_vo_arrays", "vo_host_load_calibration", "vo_host_load_poses", "vo_host_save_poses",
-           "vo_host_remove_points"]
+           "vo_host_remove_points", "vo_host_create_match_matrix", "vo_host_ba_create", "vo_host_ba_destroy",
+           "vo_host_ba_add_key_frame", "vo_host_ba_counts", "vo_host_ba_features", "vo_host_ba_pair",
+           "vo_host_ba_match_matrix", "vo_host_ba_points"]
 _lib = None
 
 
@@ -28,6 +30,17 @@ def lib():
         _lib.vo_host_vo_add_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
         _lib.vo_host_vo_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         _lib.vo_host_vo_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        _lib.vo_host_ba_create.restype = C.c_void_p
+        _lib.vo_host_ba_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        _lib.vo_host_ba_destroy.argtypes = [C.c_void_p]
+        _lib.vo_host_ba_destroy.restype = None
+        _lib.vo_host_ba_add_key_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_char_p, C.c_int]
+        _lib.vo_host_ba_counts.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        _lib.vo_host_ba_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        _lib.vo_host_ba_pair.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
+        _lib.vo_host_ba_match_matrix.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.vo_host_ba_points.argtypes = [C.c_void_p] * 4
     return _lib
 
 
@@ -152,3 +165,92 @@ def kitti_sequence_errors(gt, res, step=10, lengths=KITTI_LENGTHS):
     if not t_err:
         return None
     return float(np.mean(t_err)), float(np.mean(r_err)), len(t_err)
+
+
+# ---- feature tracks and the bundle-adjustment front end ------------------------------------------------
+def create_match_matrix(pairs, pose_count):
+    """createMatchMatrix of the C++ mirror.  pairs: list of (src_img_idx, dst_img_idx, queryIdx[], trainIdx[],
+    inliers_mask[]).  Returns the rows x pose_count int matrix (-1 = no keypoint)."""
+    src = np.array([p[0] for p in pairs], np.int32)
+    dst = np.array([p[1] for p in pairs], np.int32)
+    off = np.concatenate([[0], np.cumsum([len(p[2]) for p in pairs])]).astype(np.int32)
+    q = np.concatenate([np.asarray(p[2], np.int32) for p in pairs] + [np.zeros(0, np.int32)])
+    t = np.concatenate([np.asarray(p[3], np.int32) for p in pairs] + [np.zeros(0, np.int32)])
+    inl = np.concatenate([np.asarray(p[4], np.uint8) for p in pairs] + [np.zeros(0, np.uint8)])
+    cap = max(len(q), 1)
+    out = np.full((cap, pose_count), -7, np.int32)
+    n = C.c_int(0)
+    rc = lib().vo_host_create_match_matrix(_p(src), _p(dst), _p(off), len(pairs), _p(q), _p(t), _p(inl), int(pose_count),
+                                           _p(out), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("createMatchMatrix failed (image index outside pose_count?)")
+    return out[: n.value].copy()
+
+
+class HostBundleAdjustment:
+    """BundleAdjustment front end of the C++ host mirror (reference: src/sfm/bundle_adjustment.cpp:16-130):
+    init + addKeyFrame; match matrix and setPBAPoints() outputs for an optimiser."""
+
+    KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                         ("octave", "<i4"), ("class_id", "<i4")])
+    DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+    def __init__(self, K, max_frames=4, nfeatures=2000):
+        self.L = lib()
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        err = C.create_string_buffer(512)
+        self.h = self.L.vo_host_ba_create(_p(K), int(max_frames), int(nfeatures), err, 512)
+        if not self.h:
+            raise RuntimeError("BundleAdjustment: " + err.value.decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vo_host_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_key_frame(self, gray, pose_R, pose_t):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        R = np.ascontiguousarray(pose_R, np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(pose_t, np.float64).reshape(3)
+        err = C.create_string_buffer(512)
+        if self.L.vo_host_ba_add_key_frame(self.h, _p(gray), gray.shape[1], gray.shape[0], _p(R), _p(t), err, 512) != 0:
+            raise RuntimeError("addKeyFrame: " + err.value.decode())
+
+    def counts(self):
+        v = [C.c_int(0) for _ in range(4)]
+        self.L.vo_host_ba_counts(self.h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)  # frames, pairs, tracks, points
+
+    def features(self, frame, cap=32768):
+        kp = np.zeros(cap, self.KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        assert self.L.vo_host_ba_features(self.h, int(frame), _p(kp), _p(desc), cap, C.byref(n)) == 0
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def pair(self, p, cap=32768):
+        m = np.zeros(cap, self.DM_DTYPE)
+        inl = np.zeros(cap, np.uint8)
+        src, dst, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        assert self.L.vo_host_ba_pair(self.h, int(p), C.byref(src), C.byref(dst), _p(m), _p(inl), cap, C.byref(n)) == 0
+        return src.value, dst.value, m[: n.value].copy(), inl[: n.value].copy()
+
+    def match_matrix(self):
+        nf, _, nr, _ = self.counts()
+        out = np.zeros((max(nr, 1), nf), np.int32)
+        self.L.vo_host_ba_match_matrix(self.h, _p(out))
+        return out[:nr]
+
+    def points(self):
+        nf, _, _, npts = self.counts()
+        P = np.zeros((max(npts, 1), 3))
+        vis = np.zeros((max(npts, 1), nf), np.uint8)
+        img = np.zeros((max(npts, 1), nf, 2), np.float32)
+        self.L.vo_host_ba_points(self.h, _p(P), _p(vis), _p(img))
+        return P[:npts], vis[:npts], img[:npts]
