@@ -51,6 +51,7 @@ void launch_est_finish(hipStream_t st, EstState* s, const double2* x1, const dou
 void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps, const double2* x1,
                  const double2* x2, const int* d_n, int n_host, int n_cap, int n_grid, const uint8_t* mask_in,
                  double dist, double* q4, uint8_t* cmask, uint8_t* mask_out, double* pts4, int npairs);
+void launch_fill_subsets(hipStream_t st, uint64_t seed, int iters, int maxn, uint16_t* out);
 void launch_triangulate(hipStream_t st, const double* P, const float2* p0, const float2* p1, int n, double* pts3);
 
 #endif

@@ -626,6 +626,44 @@ void launch_pack_results(hipStream_t st, const PackArgs& a, int total_dw, uint32
     hipLaunchKernelGGL(k_pack_results, dim3(cdiv(total_dw, 256)), dim3(256), 0, st, a, out);
 }
 
+// cv::RNG (multiply-with-carry) + PointSetRegistrator::getSubset: the 5-subsets of iteration 0 .. iters-1 for
+// every point count n.  The generator state is carried from one iteration to the next and a
+// draw is repeated while it collides with an earlier pick, so the sequence of one n is sequential: one
+// thread per n (8 449 threads of ~50 k integer operations at the defaults, a fraction of a millisecond).
+__global__ __launch_bounds__(64) void k_fill_subsets(unsigned long long seed, int iters, int maxn,
+                                                     uint16_t* __restrict__ out) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n > maxn) return;
+    uint16_t* o = out + (size_t)n * iters * 5;
+    if (n < 5) {
+        for (int i = 0; i < iters * 5; i++) o[i] = 0;
+        return;
+    }
+    unsigned long long state = seed ? seed : 0xffffffffull;
+    for (int it = 0; it < iters; it++) {
+        int idx[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            for (;;) {
+                state = (unsigned long long)(uint32_t)state * 4164903690ull + (uint32_t)(state >> 32);
+                const int v = (int)((uint32_t)state % (uint32_t)n);
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < 5; j++) dup |= j < i && idx[j] == v;
+                idx[i] = v;
+                if (!dup) break;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) o[(size_t)it * 5 + i] = (uint16_t)idx[i];
+    }
+}
+
+void launch_fill_subsets(hipStream_t st, uint64_t seed, int iters, int maxn, uint16_t* out) {
+    hipLaunchKernelGGL(k_fill_subsets, dim3(cdiv(maxn + 1, 64)), dim3(64), 0, st, (unsigned long long)seed, iters, maxn,
+                       out);
+}
+
 void launch_triangulate(hipStream_t st, const double* P, const float2* p0, const float2* p1, int n, double* pts3) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_triangulate, dim3(cdiv(n, 256)), dim3(256), 0, st, P, p0, p1, n, pts3);

@@ -12,36 +12,6 @@
 
 namespace {
 
-// cv::RNG (multiply-with-carry) and PointSetRegistrator::getSubset: the 5-subsets depend only on
-// the seed and the point count, so they are tabulated once per context for every n and kept in
-// HBM; the kernels then need no host round trip to learn n.
-struct CvRng {
-    uint64_t state;
-    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffu) {}
-    uint32_t next() {
-        state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
-        return (uint32_t)state;
-    }
-    int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
-};
-
-void fill_subsets(uint64_t seed, int n, int iters, uint16_t* out) {
-    CvRng rng(seed);
-    for (int it = 0; it < iters; it++) {
-        int idx[5];
-        for (int i = 0; i < 5; i++) {
-            for (;;) {
-                const int v = idx[i] = rng.uniform(0, n);
-                int j;
-                for (j = 0; j < i; j++)
-                    if (v == idx[j]) break;
-                if (j == i) break;
-            }
-        }
-        for (int i = 0; i < 5; i++) out[(size_t)it * 5 + i] = (uint16_t)idx[i];
-    }
-}
-
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.);
     p = std::min(p, 1.);
@@ -55,29 +25,30 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)std::lrint(num / denom);
 }
 
-// One table per (device, seed, iters, maxn), shared by the contexts that ask for it.
-std::shared_ptr<SampleTable> samples_acquire(int device, uint64_t seed, int iters, int maxn) {
+// cv::RNG 5-subsets depend only on the seed and the point count, and the kernels learn a
+// pair's point count on the device, so the subsets of every n are tabulated in HBM: uint16 [maxn + 1][iters][5]
+// (85 MB at the defaults, 346 MB at 4 096 iterations).  The table is filled ON the device (k_fill_subsets: a
+// fraction of a millisecond), so a first call or a change of seed costs one short launch, not a host build
+// and a copy.  One table per (device, seed, iters, maxn), shared by the contexts that ask for it.
+#define VO_SAMPLE_TABLE_MAX_BYTES ((size_t)2 << 30)
+std::shared_ptr<SampleTable> samples_acquire(int device, hipStream_t st, uint64_t seed, int iters, int maxn) {
     static std::mutex mu;
     static std::vector<std::weak_ptr<SampleTable>> cache;
     std::lock_guard<std::mutex> lock(mu);
     for (auto& w : cache)
         if (auto t = w.lock())
             if (t->device == device && t->seed == seed && t->iters >= iters && t->maxn >= maxn) return t;
-    std::vector<uint16_t> tab((size_t)(maxn + 1) * iters * 5, 0);
-    const int nthreads = 8;
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; t++)
-        th.emplace_back([&, t]() {
-            for (int n = 5 + t; n <= maxn; n += nthreads) fill_subsets(seed, n, iters, &tab[(size_t)n * iters * 5]);
-        });
-    for (auto& x : th) x.join();
+    const size_t bytes = (size_t)(maxn + 1) * iters * 5 * sizeof(uint16_t);
+    if (bytes > VO_SAMPLE_TABLE_MAX_BYTES) return nullptr;
     auto t = std::make_shared<SampleTable>();
     t->device = device;
     t->seed = seed;
     t->iters = iters;
     t->maxn = maxn;
-    if (hipMalloc(&t->p, tab.size() * sizeof(uint16_t)) != hipSuccess) return nullptr;
-    if (hipMemcpy(t->p, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (hipMalloc(&t->p, bytes) != hipSuccess) return nullptr;
+    launch_fill_subsets(st, seed, iters, maxn, static_cast<uint16_t*>(t->p));
+    // other contexts of this device may pick the table up from the cache: it must be complete first
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return nullptr;
     cache.erase(std::remove_if(cache.begin(), cache.end(), [](const std::weak_ptr<SampleTable>& w) { return w.expired(); }),
                 cache.end());
     cache.push_back(t);
@@ -100,8 +71,11 @@ int geom_prepare(vo_ctx* c, int npairs, int n_cap, uint64_t seed, int H) {
     if (H < 1 || H > 65536) return c->fail(VO_ERR_INVALID, "max_iters %d out of range", H);
     if (!c->samples || c->samples->seed != seed || c->samples->iters < H || c->samples->maxn < c->lim.max_points) {
         VO_HIP(c, hipStreamSynchronize(c->stream));  // the stream may still read the old table
-        c->samples = samples_acquire(c->device, seed, std::max(H, 1000), c->lim.max_points);
-        if (!c->samples) return c->fail(VO_ERR_DEVICE, "could not build the RANSAC sample table");
+        c->samples = samples_acquire(c->device, c->stream, seed, std::max(H, 1000), c->lim.max_points);
+        if (!c->samples)
+            return c->fail(VO_ERR_CAPACITY, "RANSAC sample table: (max_points + 1) x max_iters x 10 bytes = %.1f GB "
+                           "(limit 2 GB, or the device is out of memory): lower vo_limits.max_points or max_iters",
+                           (double)(c->lim.max_points + 1) * std::max(H, 1000) * 10 / 1e9);
     }
     const size_t np = (size_t)npairs;
     VO_TRY(vo_ensure(c, c->d_x1, np * n_cap * sizeof(double2)));
