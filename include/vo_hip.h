@@ -139,6 +139,25 @@ int vo_recover_pose(vo_ctx* ctx, const double* E, const float* p0, const float* 
                     const double* K, double dist_thresh, uint8_t* mask_inout, double* R, double* t,
                     double* pts4d, int* n_good);
 
+/* updatePose()'s two cv calls as one submission: cv::findEssentialMat(p0, p1, K, method, prob, threshold, mask)
+ * followed by cv::recoverPose(E, p0, p1, K, R, t, dist_thresh, mask, pts4d) on the same points with the mask
+ * passed through (reference: src/visual_odometry/vo_pose.h:14,19).  Same outputs as vo_find_essential +
+ * vo_recover_pose; the points cross the bus once and the host waits once.  mask (n bytes: the mask after
+ * recoverPose), pts4d (4 x n) and n_good may be NULL.  VO_ERR_FAILED when no E is found: E and mask are zero, R
+ * and t untouched. */
+int vo_essential_pose(vo_ctx* ctx, const float* p0, const float* p1, int n, const double* K, int method,
+                      double prob, double threshold, uint64_t seed, int max_iters, double dist_thresh, double* E,
+                      uint8_t* mask, double* R, double* t, double* pts4d, int* n_good);
+
+/* The minimal solver inside cv::findEssentialMat (EMEstimatorCallback::runKernel, calib3d/src/five-point.cpp;
+ * the reference reaches it only through src/matcher/matcher.cpp:42 and src/visual_odometry/vo_pose.h:14), exposed
+ * so that a caller - and the parity tests - can run it on chosen samples.  x1, x2: count x 5 K-normalised
+ * correspondences (x, y interleaved, 10 doubles a problem).  variant 0: one problem per lane (the solver of the
+ * large RANSAC rounds); 1: one problem per 16-lane group (the solver of the small ones).  models: count x 10 x 9
+ * (row-major E, unit Frobenius norm, ascending root; unused slots zero), nmodels: count. */
+int vo_five_point(vo_ctx* ctx, const double* x1, const double* x2, int count, int variant, double* models,
+                  int* nmodels);
+
 /* triangulate(points0, points1, P0, P1): cv::triangulatePoints + points4DToVec
  * reference: src/sfm/triangulation.cpp:46-66,13-22. pts3d: n x 3. */
 int vo_triangulate(vo_ctx* ctx, const float* p0, const float* p1, int n, const double* P0,

@@ -234,6 +234,27 @@ class VoContext:
                                            _p(m), _p(R), _p(t), _p(pts), C.byref(ng)))
         return ng.value, R, t, m, pts[:, :n].copy()
 
+    def essential_pose(self, p0, p1, K, method=RANSAC, prob=0.999, threshold=1.0, seed=2**64 - 1, max_iters=1000,
+                       dist_thresh=200.0):
+        """find_essential + recover_pose in one submission. Returns (rc, E, n_good, R, t, mask, pts4d)."""
+        p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        n = p0.shape[0]
+        E = np.zeros((3, 3))
+        R = np.zeros((3, 3))
+        t = np.zeros(3)
+        mask = np.zeros(max(n, 1), np.uint8)
+        pts = np.zeros((4, max(n, 1)))
+        if n > 0:
+            pts = np.zeros((4, n))
+        ng = C.c_int(0)
+        rc = self.L.vo_essential_pose(self.h, _p(p0), _p(p1), n, _p(K), int(method), C.c_double(prob),
+                                      C.c_double(threshold), C.c_uint64(seed & (2**64 - 1)), int(max_iters),
+                                      C.c_double(dist_thresh), _p(E), _p(mask), _p(R), _p(t), _p(pts), C.byref(ng))
+        self._check(rc, allow=(VO_ERR_FAILED,))
+        return rc, E, ng.value, R, t, mask[:n].copy(), pts[:, :n].copy()
+
     def triangulate(self, p0, p1, P0, P1):
         p0 = np.ascontiguousarray(p0, np.float32).reshape(-1, 2)
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
@@ -243,6 +264,16 @@ class VoContext:
         out = np.zeros((n, 3))
         self._check(self.L.vo_triangulate(self.h, _p(p0), _p(p1), n, _p(P0), _p(P1), _p(out)))
         return out
+
+    def five_point(self, x1, x2, variant=1):
+        """count x 5 x 2 normalised correspondences -> (models count x 10 x 3 x 3, nmodels count)."""
+        x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 10)
+        x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 10)
+        n = x1.shape[0]
+        models = np.zeros((n, 10, 3, 3))
+        nm = np.zeros(n, np.int32)
+        self._check(self.L.vo_five_point(self.h, _p(x1), _p(x2), n, int(variant), _p(models), _p(nm)))
+        return models, nm
 
     def projection_matrix(self, K, pose):
         K = np.ascontiguousarray(K, np.float64)

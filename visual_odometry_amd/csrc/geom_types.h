@@ -38,6 +38,8 @@ void launch_est_init(hipStream_t st, EstState* s, const int* d_n, int n_host, in
                      int npairs);
 void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const CamK* cam, const EstState* s,
                       const int* d_n, int n_host, int n_cap, int n_grid, double2* x1, double2* x2, int npairs);
+void launch_five_point_batch(hipStream_t st, int count, bool coop, const double* x1, const double* x2, double* models,
+                             int* nmodels);
 void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
                    const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H, int npairs);
 void launch_score(hipStream_t st, int h0, int h1, const EstState* s, const double2* x1, const double2* x2, int n_cap,

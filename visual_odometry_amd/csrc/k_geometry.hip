@@ -19,6 +19,9 @@
 #include "kernels.h"
 #include "geom_types.h"
 #include "five_point.h"
+#include "five_point_coop.h"
+
+#define VO_SOLVE_COOP_MAX 16384  // hypotheses per launch up to which the cooperative solver is used
 
 namespace {
 
@@ -111,6 +114,61 @@ __global__ __launch_bounds__(LANES) void k_solve5(int h0, int h1, const EstState
     LaneScratch<LANES> s{lds + lane};
     const size_t slot = (size_t)pair * H + h;
     nmodels[slot] = five_point_solve(a, b, s, models + slot * 90);
+}
+
+// One hypothesis per 16-lane group, four per wave (five_point_coop.h): the dependent chain of a hypothesis is
+// a few thousand operations instead of ~25 k, which is what a launch of a few thousand hypotheses (the first
+// RANSAC rounds, LMedS on one pair) waits for.
+__global__ __launch_bounds__(64) void k_solve5_coop(int h0, int h1, const EstState* __restrict__ st,
+                                                    const uint16_t* __restrict__ samples, int samples_iters,
+                                                    const double2* __restrict__ x1, const double2* __restrict__ x2,
+                                                    int n_cap, double* __restrict__ models,
+                                                    int* __restrict__ nmodels, int H) {
+    __shared__ double lds[FPC_SLAB * 4];
+    const int pair = blockIdx.y, grp = threadIdx.x / FPC_G, gl = threadIdx.x % FPC_G;
+    const int cap = min(h1, st[pair].niters);
+    const int h = h0 + blockIdx.x * 4 + grp;
+    if (h >= cap) return;
+    const int n = st[pair].n;
+    const uint16_t* sidx = samples + ((size_t)n * samples_iters + h) * 5;
+    double a[10], b[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int id = sidx[k];
+        const double2 u = x1[(size_t)pair * n_cap + id], v = x2[(size_t)pair * n_cap + id];
+        a[2 * k] = u.x;
+        a[2 * k + 1] = u.y;
+        b[2 * k] = v.x;
+        b[2 * k + 1] = v.y;
+    }
+    const size_t slot = (size_t)pair * H + h;
+    const int nm = five_point_solve_coop(a, b, lds + FPC_SLAB * grp, gl, models + slot * 90);
+    if (gl == 0) nmodels[slot] = nm;
+}
+
+// vo_five_point: `count` independent minimal problems (10 doubles per view and problem), either solver.
+template <bool COOP>
+__global__ __launch_bounds__(64) void k_five_point_batch(int count, const double* __restrict__ x1,
+                                                         const double* __restrict__ x2, double* __restrict__ models,
+                                                         int* __restrict__ nmodels) {
+    constexpr int PER_BLOCK = COOP ? 4 : 16;
+    __shared__ double lds[COOP ? FPC_SLAB * 4 : FP_SCRATCH * 16];
+    const int sub = COOP ? threadIdx.x / FPC_G : threadIdx.x, gl = threadIdx.x % FPC_G;
+    const int h = blockIdx.x * PER_BLOCK + sub;
+    if (h >= count || (!COOP && threadIdx.x >= 16)) return;
+    double a[10], b[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        a[k] = x1[(size_t)h * 10 + k];
+        b[k] = x2[(size_t)h * 10 + k];
+    }
+    if (COOP) {
+        const int nm = five_point_solve_coop(a, b, lds + FPC_SLAB * sub, gl, models + (size_t)h * 90);
+        if (gl == 0) nmodels[h] = nm;
+    } else {
+        LaneScratch<16> s{lds + sub};
+        nmodels[h] = five_point_solve(a, b, s, models + (size_t)h * 90);
+    }
 }
 
 // One wave per hypothesis; its models are staged in LDS, every point is loaded once.
@@ -555,6 +613,14 @@ void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const 
 void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
                    const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H,
                    int npairs) {
+    // cooperative solver while the launch leaves SIMDs idle with one hypothesis per lane
+    static const int env_coop = getenv("VO_SOLVE_COOP") ? atoi(getenv("VO_SOLVE_COOP")) : -1;
+    const long total = (long)(h1 - h0) * npairs;
+    if (env_coop >= 0 ? env_coop != 0 : total <= VO_SOLVE_COOP_MAX) {
+        hipLaunchKernelGGL(k_solve5_coop, dim3(cdiv(h1 - h0, 4), npairs), dim3(64), 0, st, h0, h1, s, samples,
+                           samples_iters, x1, x2, n_cap, models, nmodels, H);
+        return;
+    }
     int lanes = 64;
     while (lanes > 4 && (long)(h1 - h0) * npairs / lanes < 1024) lanes /= 2;
     static const int env_lanes = getenv("VO_SOLVE_LANES") ? atoi(getenv("VO_SOLVE_LANES")) : 0;
@@ -572,6 +638,17 @@ void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint
         default: VO_SOLVE5(64); break;
     }
 #undef VO_SOLVE5
+}
+
+void launch_five_point_batch(hipStream_t st, int count, bool coop, const double* x1, const double* x2, double* models,
+                             int* nmodels) {
+    if (count <= 0) return;
+    if (coop)
+        hipLaunchKernelGGL(k_five_point_batch<true>, dim3(cdiv(count, 4)), dim3(64), 0, st, count, x1, x2, models,
+                           nmodels);
+    else
+        hipLaunchKernelGGL(k_five_point_batch<false>, dim3(cdiv(count, 16)), dim3(64), 0, st, count, x1, x2, models,
+                           nmodels);
 }
 
 void launch_score(hipStream_t st, int h0, int h1, const EstState* s, const double2* x1, const double2* x2, int n_cap,

@@ -260,6 +260,75 @@ int vo_recover_pose(vo_ctx* c, const double* E, const float* p0, const float* p1
     return VO_OK;
 }
 
+// findEssentialMat followed by recoverPose on the same points, as updatePose() calls them (reference:
+// src/visual_odometry/vo_pose.h:14,19), in ONE submission: the points go up once, E and the inlier mask stay on
+// the device between the two, and the host waits once.  Same results as vo_find_essential + vo_recover_pose with
+// the mask passed through.
+int vo_essential_pose(vo_ctx* c, const float* p0, const float* p1, int n, const double* K, int method, double prob,
+                      double threshold, uint64_t seed, int max_iters, double dist_thresh, double* E, uint8_t* mask,
+                      double* R, double* t, double* pts4d, int* n_good) {
+    if (!c) return VO_ERR_INVALID;
+    if (n < 0 || !K || !E || !R || !t || (n > 0 && (!p0 || !p1)) || !(prob > 0 && prob < 1) ||
+        (method != VO_RANSAC && method != VO_LMEDS) || max_iters < 1)
+        return c->fail(VO_ERR_INVALID, "vo_essential_pose: bad argument");
+    VO_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < 9; i++) E[i] = 0;
+    if (mask && n > 0) memset(mask, 0, n);
+    if (n_good) *n_good = 0;
+    if (n < 5) return c->fail(VO_ERR_FAILED, "vo_essential_pose: %d points, 5 needed", n);
+    VO_TRY(vo_xfer_begin(c));
+    VO_TRY(geom_prepare(c, 1, n, seed, max_iters));
+    VO_TRY(upload_points(c, p0, p1, n));
+    VO_TRY(geom_find_essential_dev(c, 1, n, c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), nullptr, n, K, method,
+                                   prob, threshold, max_iters));
+    const double* d_E = reinterpret_cast<const double*>(c->d_state.as<char>() + offsetof(EstState, E));
+    VO_TRY(geom_recover_pose_dev(c, 1, n, d_E, 0, nullptr, nullptr, nullptr, n, K, dist_thresh, true));
+    VO_TRY(vo_ensure_pinned(c, c->h_state, sizeof(EstState)));
+    VO_TRY(vo_ensure_pinned(c, c->h_pose, sizeof(PoseState)));
+    VO_HIP(c, hipMemcpyAsync(c->h_state.p, c->d_state.p, sizeof(EstState), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_pose.p, c->d_pose.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
+    if (mask) VO_TRY(vo_xfer_out(c, mask, c->d_pmask.p, n));
+    if (pts4d) VO_TRY(vo_xfer_out(c, pts4d, c->d_pts4.p, (size_t)4 * n * sizeof(double)));  // n_cap == n: rows adjoin
+    VO_TRY(vo_xfer_finish(c));
+    const EstState* s = c->h_state.as<EstState>();
+    if (s->status != VO_OK) {
+        if (mask) memset(mask, 0, n);
+        if (pts4d) memset(pts4d, 0, (size_t)4 * n * sizeof(double));
+        return c->fail(VO_ERR_FAILED, "vo_essential_pose: no model found");
+    }
+    memcpy(E, s->E, 9 * sizeof(double));
+    const PoseState* ps = c->h_pose.as<PoseState>();
+    memcpy(R, ps->R, 9 * sizeof(double));
+    memcpy(t, ps->tt, 3 * sizeof(double));
+    if (n_good) *n_good = ps->n_good;
+    return VO_OK;
+}
+
+int vo_five_point(vo_ctx* c, const double* x1, const double* x2, int count, int variant, double* models,
+                  int* nmodels) {
+    if (!c) return VO_ERR_INVALID;
+    if (count < 0 || (variant != 0 && variant != 1) || (count > 0 && (!x1 || !x2 || !models || !nmodels)))
+        return c->fail(VO_ERR_INVALID, "vo_five_point: bad argument");
+    if (count > (1 << 20)) return c->fail(VO_ERR_CAPACITY, "vo_five_point: %d problems, at most %d a call", count, 1 << 20);
+    if (count == 0) return VO_OK;
+    VO_HIP(c, hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)count * 10 * sizeof(double);
+    VO_TRY(vo_ensure(c, c->d_x1, in_bytes));
+    VO_TRY(vo_ensure(c, c->d_x2, in_bytes));
+    VO_TRY(vo_ensure(c, c->d_models, (size_t)count * 90 * sizeof(double)));
+    VO_TRY(vo_ensure(c, c->d_nmodels, (size_t)count * sizeof(int)));
+    VO_TRY(vo_xfer_begin(c));
+    VO_TRY(vo_xfer_in(c, c->d_x1.p, x1, in_bytes));
+    VO_TRY(vo_xfer_in(c, c->d_x2.p, x2, in_bytes));
+    VO_HIP(c, hipMemsetAsync(c->d_models.p, 0, (size_t)count * 90 * sizeof(double), c->stream));
+    launch_five_point_batch(c->stream, count, variant == 1, c->d_x1.as<double>(), c->d_x2.as<double>(),
+                            c->d_models.as<double>(), c->d_nmodels.as<int>());
+    VO_TRY(vo_check_launch(c, "five_point"));
+    VO_TRY(vo_xfer_out(c, models, c->d_models.p, (size_t)count * 90 * sizeof(double)));
+    VO_TRY(vo_xfer_out(c, nmodels, c->d_nmodels.p, (size_t)count * sizeof(int)));
+    return vo_xfer_finish(c);
+}
+
 int vo_triangulate(vo_ctx* c, const float* p0, const float* p1, int n, const double* P0, const double* P1,
                    double* pts3d) {
     if (!c) return VO_ERR_INVALID;

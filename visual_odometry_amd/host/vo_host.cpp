@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <random>
 
 #include <map>
@@ -85,6 +87,38 @@ void check(vo_ctx* ctx, int rc) {
 }  // namespace vo
 
 using vo::check;
+
+// ---- VO_HOST_TIMING=1: wall time per stage of the per-frame driver, printed when the process ends -------
+namespace {
+struct StageTimers {
+    static constexpr int N = 10;
+    const char* names[N] = {"image copy in", "frame buffer", "detectFAST", "vo_lk_track", "removePoints",
+                            "vo_essential_pose", "points4DToVec", "getScale", "pose compose", "other"};
+    double sec[N] = {0};
+    long calls[N] = {0};
+    bool on = std::getenv("VO_HOST_TIMING") != nullptr;
+    ~StageTimers() {
+        if (!on) return;
+        for (int i = 0; i < N; i++)
+            if (calls[i])
+                std::fprintf(stderr, "[vo_host timing] %-18s %6ld calls  %8.1f us each\n", names[i], calls[i],
+                             sec[i] / calls[i] * 1e6);
+    }
+};
+StageTimers g_timers;
+struct StageScope {
+    int i;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageScope(int idx) : i(idx) {
+        if (g_timers.on) t0 = std::chrono::steady_clock::now();
+    }
+    ~StageScope() {
+        if (!g_timers.on) return;
+        g_timers.sec[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        g_timers.calls[i]++;
+    }
+};
+}  // namespace
 
 // ---- FeatureDetector ------------------------------------------------------------------------
 FeatureDetector::FeatureDetector(int orb_nfeatures) {
@@ -451,16 +485,21 @@ int updatePose(const vo::Matd& K, VOFrame* last_frame, VOFrame* new_frame) {
 
     new_frame->E = vo::Matd(3, 3);
     new_frame->mask.d.assign(n, 0);
-    int rc = vo_find_essential(ctx, p0, p1, n, K.d.data(), VO_LMEDS, 0.999, 1.0, ~(uint64_t)0, 1000,
-                               new_frame->E.d.data(), new_frame->mask.d.data());
+    // findEssentialMat(LMEDS) and recoverPose (vo_pose.h:14,19) as one submission: the mask recoverPose
+    // receives is the one findEssentialMat left, the mask kept is recoverPose's
     int res = 0;
     vo::Matd points_4d(4, n);
     new_frame->local_R = vo::Matd(3, 3);
     new_frame->local_t = vo::Matd(3, 1);
+    int rc;
+    {
+        StageScope ts(5);
+        rc = vo_essential_pose(ctx, p0, p1, n, K.d.data(), VO_LMEDS, 0.999, 1.0, ~(uint64_t)0, 1000, kMax3DDist,
+                               new_frame->E.d.data(), new_frame->mask.d.data(), new_frame->local_R.d.data(),
+                               new_frame->local_t.d.data(), points_4d.d.data(), &res);
+    }
     if (rc == VO_OK) {
-        check(ctx, vo_recover_pose(ctx, new_frame->E.d.data(), p0, p1, n, K.d.data(), kMax3DDist,
-                                   new_frame->mask.d.data(), new_frame->local_R.d.data(),
-                                   new_frame->local_t.d.data(), points_4d.d.data(), &res));
+        StageScope ts(6);
         new_frame->points_3d = points4DToVec(points_4d);
     } else if (rc != VO_ERR_FAILED) {
         check(ctx, rc);
@@ -469,7 +508,10 @@ int updatePose(const vo::Matd& K, VOFrame* last_frame, VOFrame* new_frame) {
         new_frame->local_t = -new_frame->local_t;
         new_frame->local_R = new_frame->local_R.t();
         new_frame->local_pose = vo::hconcat(new_frame->local_R, new_frame->local_t);
-        new_frame->scale = getScale(*last_frame, *new_frame, kMinPosePoints, 200, kMax3DDist);
+        {
+            StageScope ts(7);
+            new_frame->scale = getScale(*last_frame, *new_frame, kMinPosePoints, 200, kMax3DDist);
+        }
         new_frame->pose_t = last_frame->pose_t + (double)new_frame->scale * (last_frame->pose_R * new_frame->local_t);
         new_frame->pose_R = new_frame->local_R * last_frame->pose_R;
         new_frame->pose = vo::hconcat(new_frame->pose_R, new_frame->pose_t);
@@ -523,11 +565,15 @@ float FeatureTracker::trackPoints(VOFrame* vo0, VOFrame* vo1) {
     const bool cached = cached_id_ != 0 && cached_id_ == a.id;
     cached_id_ = 0;
     static_assert(sizeof(vo::Point2f) == 8, "packed points");
-    check(ctx_, vo_lk_track(ctx_, cached ? nullptr : a.px.data(), b.px.data(), a.width, a.height, a.width,
-                            n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
-                            n ? status.data() : nullptr));
+    {
+        StageScope ts(3);
+        check(ctx_, vo_lk_track(ctx_, cached ? nullptr : a.px.data(), b.px.data(), a.width, a.height, a.width,
+                                n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
+                                n ? status.data() : nullptr));
+    }
     cached_id_ = b.id;
     // Remove bad points
+    StageScope ts(4);
     return (float)removePoints(vo0, vo1, &status);
 }
 
@@ -535,6 +581,33 @@ float FeatureTracker::trackPoints(VOFrame* vo0, VOFrame* vo1) {
 // moves elements behind i, which the loop has already visited, so every decision sees original
 // data and the result is this stable compaction.  `dists` is sorted first and then erased by the
 // ORIGINAL point index: kept as is (utils.h:16,42,57).
+namespace {
+// Ascending sort of floats that are norms (>= 0, or NaN, which sorts last as a bit pattern): their bit
+// patterns order like unsigned integers, so three 11-bit counting passes do it in a fraction of
+// std::sort's time for the few thousand points of a frame.  Equal values are indistinguishable, so the
+// result is the array std::sort produces.
+void sort_nonnegative(std::vector<float>* v) {
+    const size_t n = v->size();
+    bool plain = n >= 256;
+    for (size_t i = 0; i < n && plain; i++) plain = !std::signbit((*v)[i]) && !std::isnan((*v)[i]);
+    if (!plain) {
+        std::sort(v->begin(), v->end());
+        return;
+    }
+    std::vector<uint32_t> a(n), b(n);
+    memcpy(a.data(), v->data(), n * sizeof(float));
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 11 * pass;
+        uint32_t count[2049] = {0};
+        for (size_t i = 0; i < n; i++) count[((a[i] >> shift) & 2047u) + 1]++;
+        for (int k = 0; k < 2048; k++) count[k + 1] += count[k];
+        for (size_t i = 0; i < n; i++) b[count[(a[i] >> shift) & 2047u]++] = a[i];
+        a.swap(b);
+    }
+    memcpy(v->data(), a.data(), n * sizeof(float));
+}
+}  // namespace
+
 int removePoints(VOFrame* vo0, VOFrame* vo1, std::vector<unsigned char>* status) {
     const size_t n = status->size();
     std::vector<float> orig(n);
@@ -543,7 +616,7 @@ int removePoints(VOFrame* vo0, VOFrame* vo1, std::vector<unsigned char>* status)
         orig[i] = (float)std::sqrt((double)dx * dx + (double)dy * dy);  // cv::norm(Point2f) -> double -> float
     }
     std::vector<float> dists = orig;
-    std::sort(dists.begin(), dists.end());
+    sort_nonnegative(&dists);  // std::sort(dists) in the reference: the sorted ORDER is what the sums below see
     const double sum = std::accumulate(dists.begin(), dists.end(), 0.0);
     const double mean = sum / dists.size();
     const double sq_sum = std::inner_product(dists.begin(), dists.end(), dists.begin(), 0.0);
@@ -589,16 +662,20 @@ VisualOdometry::VisualOdometry(const vo::Matd& K, size_t min_tracked_points, boo
 }
 
 void VisualOdometry::addImage(const vo::Image& image, vo::Matd* pose, vo::Matd* /*pose_kalman*/) {
-    VOFrame frame;
-    frame.setImage(image);
-    if (frame_buffer_.size() == kFrameBufferCapacity) frame_buffer_.pop_front();  // circular_buffer overwrite
-    frame_buffer_.push_back(std::move(frame));
+    {
+        StageScope ts(1);
+        VOFrame frame;
+        frame.setImage(image);
+        if (frame_buffer_.size() == kFrameBufferCapacity) frame_buffer_.pop_front();  // circular_buffer overwrite
+        frame_buffer_.push_back(std::move(frame));
+    }
     if (frame_buffer_.size() != kFrameBufferCapacity) return;
 
     VOFrame& vo1 = frame_buffer_[frame_buffer_.size() - 2];
     VOFrame& vo2 = frame_buffer_[frame_buffer_.size() - 1];
 
     if (!tracking_) {
+        StageScope ts(2);
         feature_detector_.detectFAST(&vo1);
         tracking_ = true;
     }
@@ -725,7 +802,10 @@ int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, doubl
         vo::Image im;
         im.width = w;
         im.height = h;
-        im.px.assign(gray, gray + (size_t)w * h);
+        {
+            StageScope ts(0);
+            im.px.assign(gray, gray + (size_t)w * h);
+        }
         v->vo->addImage(im, &v->pose, nullptr);
         for (int i = 0; i < 12; i++) pose[i] = v->pose.d[i];
         return 0;
