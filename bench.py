@@ -402,7 +402,9 @@ def main():
                 traffic = [v for k, v in kern.items() if k.startswith("k_knn2")][0]["hbm_bytes"]
             except Exception:
                 traffic = None
-        comp = sum(compulsory_bytes(bkp[p], bkp[p + 1]) for p in range(nc))
+        # every frame's descriptor table once (it is the query side of one pair and the train side of the next:
+        # one read serves both) + the 16-byte result per query
+        comp = sum(bkp[p] * 32 for p in range(nc + 1)) + sum(bkp[p] * 16 for p in range(nc))
         scan = sum(scan_bytes(bkp[p], bkp[p + 1]) for p in range(nc))
         roofline = {
             "kernel": "k_knn2<8>", "bound": "valu", "achieved": achieved, "peak": ceiling,
