@@ -1,0 +1,94 @@
+"""Pins the oracle against OpenCV WHERE OpenCV EXISTS (SURVEY.md 8c's opportunistic test).
+
+OpenCV is absent from the build image and from the GPU box, so every test here is skipped there and the
+repository's parity stays "HIP path == oracle, oracle == OpenCV unpinned" (DESIGN.md 2).  On a machine with
+`cv2` (the reference pins 3.4.2; the integer stages below have not changed through 4.x) this file is the
+missing link: it runs cv's own FAST, ORB, BFMatcher, pyrLK, findEssentialMat and recoverPose on the
+reference's KITTI images (tests/golden/kitti/) at the reference's parameters and compares them with
+oracle/.  Nothing here touches the GPU or the product path.
+
+Expected outcome per stage, from DESIGN.md 2's list of known deviations:
+  FAST, ORB keypoints / descriptors, Hamming 2-NN      bit-exact (integer pipelines; the rBRIEF pattern table
+                                                       re-typed from memory is what this would catch)
+  pyrLK                                                points within 1e-2 px (cv's SSE2 path sums in float)
+  findEssentialMat / recoverPose                       E up to sign and R, t within 1e-6 on clean data
+"""
+import os
+
+import numpy as np
+import pytest
+
+cv2 = pytest.importorskip("cv2", reason="OpenCV is not installed: the oracle stays unpinned against it")
+from PIL import Image  # noqa: E402
+
+from visual_odometry_amd import synth  # noqa: E402
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti")
+K = synth.KITTI_K
+
+
+def load(name):
+    return np.ascontiguousarray(np.array(Image.open(os.path.join(HERE, name + ".png"))))
+
+
+def kp_table(kps):
+    return np.array([(k.pt[0], k.pt[1], k.size, k.angle, k.response, k.octave) for k in kps], np.float64)
+
+
+def oracle_table(kp):
+    return np.stack([kp["x"], kp["y"], kp["size"], kp["angle"], kp["response"], kp["octave"]], 1).astype(np.float64)
+
+
+@pytest.mark.parametrize("name", ["000000", "000003"])
+def test_fast_matches_cv(oracle, name):
+    im = load(name)
+    det = cv2.FastFeatureDetector_create(20, True, cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
+    a, b = kp_table(det.detect(im)), oracle_table(oracle.fast_detect(im, 20, True))
+    assert a.shape == b.shape and np.array_equal(a[:, :2], b[:, :2]) and np.array_equal(a[:, 4], b[:, 4])
+
+
+@pytest.mark.parametrize("nfeatures", [2000, 5000])
+def test_orb_matches_cv(oracle, nfeatures):
+    im = load("000000")
+    kps, desc = cv2.ORB_create(nfeatures).detectAndCompute(im, None)
+    ko, do = oracle.orb_detect_compute(im, oracle.orb_params(nfeatures))
+    a, b = kp_table(kps), oracle_table(ko)
+    assert a.shape == b.shape
+    assert np.array_equal(a[:, :2], b[:, :2]), "keypoint positions / order"
+    assert np.array_equal(a[:, 5], b[:, 5]), "octaves"
+    assert np.allclose(a[:, 3], b[:, 3], atol=1e-4), "angles"
+    assert np.array_equal(desc, do), "descriptors (the rBRIEF pattern table is what this pins)"
+
+
+def test_knn_matches_cv(oracle):
+    p = oracle.orb_params(2000)
+    _, d0 = oracle.orb_detect_compute(load("000000"), p)
+    _, d1 = oracle.orb_detect_compute(load("000001"), p)
+    knn = cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(d0, d1, k=2)
+    ok, nv = oracle.knn2_hamming(d0, d1)
+    for q, row in enumerate(knn):
+        assert nv[q] == len(row) == 2
+        for j in range(2):
+            assert row[j].trainIdx == ok[q, j]["trainIdx"] and row[j].distance == ok[q, j]["distance"]
+
+
+def test_lk_close_to_cv(oracle):
+    a, b = load("000000"), load("000001")
+    kp = oracle.fast_detect(a, 20, True)
+    p0 = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+    p1, st, _ = cv2.calcOpticalFlowPyrLK(a, b, p0, None)
+    q1, so = oracle.lk_track(a, b, p0, oracle.lk_params(channels=1))
+    both = (st.ravel() != 0) & (so != 0)
+    assert both.mean() > 0.9
+    assert np.percentile(np.abs(p1.reshape(-1, 2)[both] - q1[both]).max(1), 99) < 1e-2
+
+
+def test_essential_and_pose_close_to_cv(oracle):
+    p0, p1, *_ = synth.correspondences(600, seed=3, inlier_ratio=0.8)
+    E, mask = cv2.findEssentialMat(p0, p1, K, cv2.RANSAC, 0.999, 1.0)
+    rc, Eo, mo, _ = oracle.find_essential(p0, p1, K, oracle.RANSAC)
+    assert rc == 0 and min(np.abs(E - Eo).max(), np.abs(E + Eo).max()) < 1e-6
+    assert (mask.ravel() != 0).sum() == mo.sum()
+    n, R, t, _ = cv2.recoverPose(E, p0, p1, K, mask=mask.copy())
+    no, Ro, to, _, _ = oracle.recover_pose(Eo, p0, p1, K, 200.0, mo)
+    assert np.abs(R - Ro).max() < 1e-6 and np.abs(t.ravel() - to).max() < 1e-6
