@@ -149,6 +149,18 @@ int vo_essential_pose(vo_ctx* ctx, const float* p0, const float* p1, int n, cons
                       double prob, double threshold, uint64_t seed, int max_iters, double dist_thresh, double* E,
                       uint8_t* mask, double* R, double* t, double* pts4d, int* n_good);
 
+/* cv::AKAZE::create()->detectAndCompute(image, noArray(), keypoints, descriptors)
+ * reference: FeatureDetector::detectComputeAKAZE, src/features/feature_detector.cpp:7,43-45, called by
+ * BundleAdjustment::addKeyFrame (src/sfm/bundle_adjustment.cpp:41).  MLDB, full size: desc rows of
+ * VO_AKAZE_DESC_BYTES (61); keypoints in cv's order (level after level, row-major), kp.class_id = evolution
+ * level, kp.octave = its octave, angle in degrees, size = 2 esigma derivative_factor.  *n is the true count even
+ * when cap is smaller (VO_ERR_CAPACITY then).  vo_knn2_hamming takes the rows with desc_bytes = 61. */
+void vo_akaze_params_default(vo_akaze_params* p);
+int vo_akaze_detect_compute(vo_ctx* ctx, const uint8_t* gray, int w, int h, int stride, const vo_akaze_params* p,
+                            vo_keypoint* kp, uint8_t* desc, int cap, int* n);
+/* test hook: a plane of an evolution level of the last call (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet, 5 mask) */
+int vo_debug_akaze_level(vo_ctx* ctx, int level, int which, float* out, int* lw, int* lh);
+
 /* The minimal solver inside cv::findEssentialMat (EMEstimatorCallback::runKernel, calib3d/src/five-point.cpp;
  * the reference reaches it only through src/matcher/matcher.cpp:42 and src/visual_odometry/vo_pose.h:14), exposed
  * so that a caller - and the parity tests - can run it on chosen samples.  x1, x2: count x 5 K-normalised

@@ -46,6 +46,24 @@ typedef struct vo_orb_params {
     int32_t fast_threshold;/* 20 */
 } vo_orb_params;
 
+/* cv::AKAZE::create(...) arguments, in cv order.  The reference takes every default
+ * (src/features/feature_detector.cpp:7, cuda variant src/features/cuda/feature_detector.cpp:9):
+ * DESCRIPTOR_MLDB, full size (486 bits = 61 bytes), 3 channels, threshold 0.001, 4 octaves x 4 sublevels,
+ * DIFF_PM_G2.  Only MLDB / full size / PM_G2 are supported; the fields below are the ones that may vary. */
+typedef struct vo_akaze_params {
+    float threshold;          /* 0.001f: detector response threshold */
+    int32_t n_octaves;        /* 4 */
+    int32_t n_sublevels;      /* 4 (cv: nOctaveLayers) */
+    int32_t channels;         /* 3 (1..3) */
+    int32_t pattern_size;     /* 10 (AKAZEOptions::descriptor_pattern_size; even) */
+    float soffset;            /* 1.6f  base scale offset */
+    float derivative_factor;  /* 1.5f */
+    float kcontrast_percentile; /* 0.7f */
+    int32_t kcontrast_nbins;  /* 300 */
+    int32_t reserved;
+} vo_akaze_params;
+#define VO_AKAZE_DESC_BYTES 61
+
 /* cv::SparsePyrLKOpticalFlow::create(...) arguments. The reference takes every default
  * (src/features/feature_tracker.cpp:6, cuda variant src/features/cuda/feature_tracker.cpp:5);
  * vo_lk_params_default fills them in. flags are fixed at 0 (no initial flow, no eigenvalue output). */

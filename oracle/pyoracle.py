@@ -35,6 +35,20 @@ class LkParams(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class AkazeParams(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("n_octaves", C.c_int32), ("n_sublevels", C.c_int32),
+                ("channels", C.c_int32), ("pattern_size", C.c_int32), ("soffset", C.c_float),
+                ("derivative_factor", C.c_float), ("kcontrast_percentile", C.c_float),
+                ("kcontrast_nbins", C.c_int32), ("reserved", C.c_int32)]
+
+
+def akaze_params(**kw):
+    p = AkazeParams(0.001, 4, 4, 3, 10, 1.6, 1.5, 0.7, 300, 0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 def lk_params(**kw):
     p = LkParams(21, 21, 3, 30, 0.01, 1e-4, 3, 0)
     for k, v in kw.items():
@@ -340,3 +354,42 @@ def remove_points(p0, p1, status, pts3d=None, mask=None):
                                        C.byref(n3), C.byref(nm), C.byref(ret))
     assert rc == 0, rc
     return p0[: n_out.value].copy(), p1[: n_out.value].copy(), st, p3[: n3.value].copy(), mk[: nm.value].copy(), ret.value
+
+
+# ---- AKAZE ---------------------------------------------------------------------------------------
+def akaze_layout(w, h, params):
+    cap = 64
+    lw, lh, ss, bd, ns = (np.zeros(cap, np.int32) for _ in range(5))
+    es = np.zeros(cap, np.float32)
+    n = lib().vo_oracle_akaze_layout(int(w), int(h), C.byref(params), _p(lw), _p(lh), _p(ss), _p(bd), _p(es), _p(ns))
+    assert n > 0, n
+    return dict(w=lw[:n].copy(), h=lh[:n].copy(), sigma_size=ss[:n].copy(), border=bd[:n].copy(),
+                esigma=es[:n].copy(), nsteps=ns[:n].copy())
+
+
+def akaze_tau(T):
+    tau = np.zeros(256, np.float32)
+    lib().vo_oracle_akaze_tau.argtypes = [C.c_float, C.c_void_p, C.c_int]
+    n = lib().vo_oracle_akaze_tau(float(T), _p(tau), 256)
+    return tau[:n].copy()
+
+
+def akaze_level(gray, params, level, which):
+    gray = _img(gray)
+    h, w = gray.shape
+    lay = akaze_layout(w, h, params)
+    out = np.zeros((int(lay["h"][level]), int(lay["w"][level])), np.float32)
+    rc = lib().vo_oracle_akaze_level(_p(gray), w, h, w, C.byref(params), int(level), int(which), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def akaze_detect_compute(gray, params, cap=65536):
+    gray = _img(gray)
+    h, w = gray.shape
+    kp = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 61), np.uint8)
+    n = C.c_int(0)
+    rc = lib().vo_oracle_akaze_detect_compute(_p(gray), w, h, w, C.byref(params), _p(kp), _p(desc), cap, C.byref(n))
+    assert rc == 0, rc
+    return kp[: n.value].copy(), desc[: n.value].copy()

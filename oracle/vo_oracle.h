@@ -63,6 +63,24 @@ int vo_oracle_orb_detect_compute(const uint8_t* gray, int w, int h, int stride,
 int vo_oracle_orb_compute(const uint8_t* gray, int w, int h, int stride, const vo_orb_params* p,
                           vo_keypoint* kp_inout, int* n_inout, uint8_t* desc);
 
+/* ---- AKAZE ---------------------------------------------------------------- */
+
+void vo_oracle_akaze_params_default(vo_akaze_params* p);
+
+/* Evolution levels: sizes, sigma_size, border, esigma and FED step counts. Returns the number of levels. */
+int vo_oracle_akaze_layout(int w, int h, const vo_akaze_params* p, int* lw, int* lh, int* sigma_size, int* border,
+                           float* esigma, int* nsteps);
+/* fed_tau_by_process_time(T, 1, 0.25, reordering): the step sizes of one FED cycle. Returns their number. */
+int vo_oracle_akaze_tau(float T, float* tau, int cap);
+/* One plane of one evolution level, tight floats. which: 0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet, 5 keypoint mask. */
+int vo_oracle_akaze_level(const uint8_t* gray, int w, int h, int stride, const vo_akaze_params* p, int level,
+                          int which, float* out);
+/* cv::AKAZE::create()->detectAndCompute(image, noArray(), kps, desc)
+ * reference: src/features/feature_detector.cpp:7,43-45 (from src/sfm/bundle_adjustment.cpp:41).
+ * desc: rows of VO_AKAZE_DESC_BYTES (61). kp.class_id = evolution level, kp.octave = its octave. */
+int vo_oracle_akaze_detect_compute(const uint8_t* gray, int w, int h, int stride, const vo_akaze_params* p,
+                                   vo_keypoint* kp, uint8_t* desc, int cap, int* n);
+
 /* ---- tracker -------------------------------------------------------------------------- */
 
 void vo_oracle_lk_params_default(vo_lk_params* p);

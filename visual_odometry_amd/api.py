@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import OrbParams, Limits, PairParams, PairResult, LkParams, SeqOutputs
+from ._lib import OrbParams, Limits, PairParams, PairResult, LkParams, SeqOutputs, AkazeParams
 
 KP_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -30,6 +30,14 @@ class VoError(RuntimeError):
 def orb_params(nfeatures=2000, **kw):
     p = OrbParams()
     _lib.lib().vo_orb_params_default(C.byref(p), int(nfeatures))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def akaze_params(**kw):
+    p = AkazeParams()
+    _lib.lib().vo_akaze_params_default(C.byref(p))
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -263,6 +271,26 @@ class VoContext:
         n = p0.shape[0]
         out = np.zeros((n, 3))
         self._check(self.L.vo_triangulate(self.h, _p(p0), _p(p1), n, _p(P0), _p(P1), _p(out)))
+        return out
+
+    def akaze_detect_compute(self, gray, params=None, cap=65536):
+        """cv::AKAZE::create()->detectAndCompute: (keypoints, descriptors n x 61)."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        if params is None:
+            params = akaze_params()
+        kp = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 61), np.uint8)
+        n = C.c_int(0)
+        self._check(self.L.vo_akaze_detect_compute(self.h, _p(gray), w, h, w, C.byref(params), _p(kp), _p(desc), cap,
+                                                   C.byref(n)))
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def debug_akaze_level(self, level, which):
+        lw, lh = C.c_int(0), C.c_int(0)
+        self._check(self.L.vo_debug_akaze_level(self.h, int(level), int(which), None, C.byref(lw), C.byref(lh)))
+        out = np.zeros((lh.value, lw.value), np.float32)
+        self._check(self.L.vo_debug_akaze_level(self.h, int(level), int(which), _p(out), None, None))
         return out
 
     def five_point(self, x1, x2, variant=1):

@@ -113,6 +113,17 @@ struct vo_ctx {
     int tk_w = 0, tk_h = 0, tk_win_w = 0, tk_win_h = 0, tk_max_level = -1;
     int tk_last = -1;    // slot of d_tk_pyr holding the pyramid of the last call's `next` image
 
+    // ---- AKAZE workspace (vo_akaze.cpp) ------------------------------------------------------
+    DevBuf d_ak;       // float arena: work planes, then Lt / Lsmooth / Lx / Ly / Ldet of every level, AkContrast
+    DevBuf d_ak_mask;  // uint8 per pixel of every level: 3 x 3 maxima
+    DevBuf d_ak_tab;   // area-resize tables, descriptor comparison table
+    DevBuf d_ak_kp, d_ak_desc;
+    PinnedBuf h_ak;    // Ldet of every level, then the masks
+    int ak_levels = 0;
+    size_t ak_total = 0, ak_plane0 = 0;
+    std::vector<int> ak_lw, ak_lh;
+    std::vector<size_t> ak_at;
+
     // ---- matcher workspace ---------------------------------------------------------------
     DevBuf d_q, d_t;    // descriptor uploads (host-pointer entry points)
     DevBuf d_part;      // uint2 [pair][split][nq_cap]

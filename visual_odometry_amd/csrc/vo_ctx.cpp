@@ -188,12 +188,13 @@ void vo_ctx_destroy(vo_ctx* c) {
                      &c->d_x1,   &c->d_x2,    &c->d_models, &c->d_nmodels, &c->d_counts,
                      &c->d_state, &c->d_mask,   &c->d_q4,    &c->d_cmask,  &c->d_pose,   &c->d_pmask,
                      &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj,
-                     &c->d_tk_pyr[0], &c->d_tk_pyr[1], &c->d_tk_deriv, &c->d_pack};
+                     &c->d_tk_pyr[0], &c->d_tk_pyr[1], &c->d_tk_deriv, &c->d_pack,
+                     &c->d_ak, &c->d_ak_mask, &c->d_ak_tab, &c->d_ak_kp, &c->d_ak_desc};
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
                         &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img,
-                        &c->h_xfer, &c->h_pack, &c->h_dgood, &c->h_dmask};
+                        &c->h_xfer, &c->h_pack, &c->h_dgood, &c->h_dmask, &c->h_ak};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < VO_PROF_COUNT; i++) {
