@@ -103,11 +103,21 @@ int main(int argc, char** argv) {
             }
         const auto tri = triangulate(p0, p1, getProjectionMatrix(K, vo0.pose), getProjectionMatrix(K, vo1.pose));
         dump(out, "tri.bin", tri.data(), tri.size() * sizeof(vo::Point3d));
+        // AKAZE as BundleAdjustment::addKeyFrame calls it (bundle_adjustment.cpp:41); BRISK is never called by the
+        // reference and is not built: it must say so
+        {
+            std::vector<vo::KeyPoint> k;
+            vo::Descriptors d;
+            feature_detector.detectComputeAKAZE(vo0, &k, &d);
+            if (d.cols != 61 || d.rows != (int)k.size()) return 5;
+            dump(out, "akaze_kp.bin", k.data(), k.size() * sizeof(vo::KeyPoint));
+            dump(out, "akaze_desc.bin", d.d.data(), d.d.size());
+        }
         bool threw = false;
         try {
             std::vector<vo::KeyPoint> k;
             vo::Descriptors d;
-            feature_detector.detectComputeAKAZE(vo0, &k, &d);
+            feature_detector.detectComputeBRISK(vo0, &k, &d);
         } catch (const vo::Error&) {
             threw = true;
         }

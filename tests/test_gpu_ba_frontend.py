@@ -12,16 +12,20 @@ pytestmark = pytest.mark.gpu
 NF = 1200
 
 
-def test_key_frame_window_tracks_and_points(oracle):
+@pytest.mark.parametrize("descriptor", ["akaze", "orb"])  # akaze: what the reference's addKeyFrame calls (:41)
+def test_key_frame_window_tracks_and_points(oracle, descriptor):
     fr, poses, K = synth.make_sequence(5, 6)
-    ba = host_api.HostBundleAdjustment(K, max_frames=4, nfeatures=NF)
+    ba = host_api.HostBundleAdjustment(K, max_frames=4, nfeatures=NF, descriptor=descriptor)
     for k in range(6):
         ba.add_key_frame(fr[k], poses[k][:, :3], poses[k][:, 3])
     nf, npairs, nrows, npts = ba.counts()
     assert nf == 4  # the window slid twice: key frames 2..5
     win = list(range(2, 6))
-    po = oracle.orb_params(NF)
-    feats = [oracle.orb_detect_compute(fr[k], po) for k in win]
+    if descriptor == "orb":
+        po = oracle.orb_params(NF)
+        feats = [oracle.orb_detect_compute(fr[k], po) for k in win]
+    else:
+        feats = [oracle.akaze_detect_compute(fr[k], oracle.akaze_params()) for k in win]
     for c in range(4):
         kp, desc = ba.features(c)
         assert np.array_equal(kp, feats[c][0]) and np.array_equal(desc, feats[c][1])
@@ -42,6 +46,7 @@ def test_key_frame_window_tracks_and_points(oracle):
             pairs.append((i, j, good["queryIdx"], good["trainIdx"], mask))
             p += 1
     assert p == npairs == 5
+    assert all(len(q[2]) > 50 for q in pairs)
     # createMatchMatrix: the reference's loops on the same pairs
     want = reference_match_matrix(pairs, 4)
     mm = ba.match_matrix()

@@ -41,6 +41,10 @@ def test_host_mirror_matches_oracle(tmp_path, oracle):
     for i in range(2):
         assert np.array_equal(load("kp%d.bin" % i, api.KP_DTYPE), ko[i][0])
         assert np.array_equal(load("desc%d.bin" % i, np.uint8).reshape(-1, 32), ko[i][1])
+    # FeatureDetector::detectComputeAKAZE (what BundleAdjustment::addKeyFrame calls)
+    ka, da = oracle.akaze_detect_compute(frames[0], oracle.akaze_params())
+    assert np.array_equal(load("akaze_kp.bin", api.KP_DTYPE), ka)
+    assert np.array_equal(load("akaze_desc.bin", np.uint8).reshape(-1, 61), da)
     # matcher(): knn2 + ratio + gate + findEssentialMat(RANSAC)
     knn, nv = oracle.knn2_hamming(ko[0][1], ko[1][1])
     good = oracle.match_filter(knn, nv, ko[0][0], ko[1][0], 0.7, 200.0)

@@ -14,6 +14,7 @@
 
 #include "../../include/vo_hip.h"
 #include "kernels.h"
+#include "akaze_types.h"
 
 struct DevBuf {
     void* p = nullptr;
@@ -115,10 +116,21 @@ struct vo_ctx {
 
     // ---- AKAZE workspace (vo_akaze.cpp) ------------------------------------------------------
     DevBuf d_ak;       // float arena: work planes, then Lt / Lsmooth / Lx / Ly / Ldet of every level, AkContrast
-    DevBuf d_ak_mask;  // uint8 per pixel of every level: 3 x 3 maxima
+    DevBuf d_ak_mask;  // counter + AkExt list: the 3 x 3 maxima of every level with their neighbourhoods
     DevBuf d_ak_tab;   // area-resize tables, descriptor comparison table
     DevBuf d_ak_kp, d_ak_desc;
-    PinnedBuf h_ak;    // Ldet of every level, then the masks
+    PinnedBuf h_ak;    // host copy of the counter and the list
+    std::vector<uint8_t> ak_hmask;   // dense masks of all levels on the host, all zero between calls
+    std::vector<AkExt> ak_ext_sorted;
+    std::vector<int> ak_survivors;   // positions that survived the cross-level filtering (debug hook)
+    struct AkGraphKey {  // what the captured launch sequence depends on
+        int w, h;
+        vo_akaze_params prm;
+        const void *arena, *mask, *tab, *img;
+        size_t ext_cap;
+    };
+    AkGraphKey ak_key;
+    hipGraphExec_t ak_graph = nullptr;  // phase 1 of vo_akaze_detect_compute, replayed per image
     int ak_levels = 0;
     size_t ak_total = 0, ak_plane0 = 0;
     std::vector<int> ak_lw, ak_lh;

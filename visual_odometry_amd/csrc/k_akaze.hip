@@ -5,9 +5,12 @@
 // -ffp-contract=off and correctly rounded division / sqrt), so the planes are the same floats as a scalar
 // x86 evaluation.  All planes are tight (pitch = width) float images in one arena; a pixel is a thread.
 // The non-linear scale space is bandwidth-trivial at these sizes (0.47 M pixels at level 0, a quarter per
-// octave) and launch-bound: ~500 short launches per image.  What is order-dependent stays sequential where
+// octave) and launch-bound: ~300 short launches per image, replayed as one hipGraph (vo_akaze.cpp).  (A FED
+// cycle of a coarse level in ONE workgroup with Lt in LDS was tried to save its 8-29 launches: 0.4 ms per level
+// on one CU against ~5 us per step across the chip. Removed.)  What is order-dependent stays sequential where
 // the order is defined: the 109-sample orientation sums run one window per lane (each lane adds its samples
 // in index order), the MLDB cell means one cell per lane (samples in scan order).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -66,35 +69,87 @@ __global__ __launch_bounds__(256) void k_ak_gauss(const float* __restrict__ src,
     dst[i] = s;
 }
 
-// One pass of the three-tap derivative / smoothing filters (taps at distance `scale`, BORDER_REFLECT_101).
-// dir 0: along x, 1: along y.  deriv: b - a; otherwise wnorm c + norm (a + b).
-__global__ __launch_bounds__(256) void k_ak_deriv(const float* __restrict__ src, float* __restrict__ dst, int w, int h,
-                                                  int scale, float norm, float wnorm, int dir, int deriv) {
+// The separable three-tap derivative filters (taps at distance `scale`, BORDER_REFLECT_101), both passes in one
+// kernel: the row pass value T of the three rows a pixel needs is recomputed instead of stored, with the same
+// operations in the same order as the two-pass form.
+//   d/dx:  T(y, x) = S(y, x + s) - S(y, x - s);                out = wnorm T(y, x) + norm (T(y - s, x) + T(y + s, x))
+//   d/dy:  T(y, x) = wnorm S(y, x) + norm (S(y, x - s) + S(y, x + s));   out = T(y + s, x) - T(y - s, x)
+struct Tap3 {
+    int xm, xp, ym, yp;  // reflected neighbour coordinates
+};
+__device__ __forceinline__ Tap3 tap3(int x, int y, int w, int h, int s) {
+    return {reflect101(x - s, w), reflect101(x + s, w), reflect101(y - s, h), reflect101(y + s, h)};
+}
+__device__ __forceinline__ float ddx(const float* __restrict__ S, int w, int x, int y, const Tap3& t, float norm,
+                                     float wnorm) {
+    const float tc = S[y * w + t.xp] - S[y * w + t.xm];
+    const float ta = S[t.ym * w + t.xp] - S[t.ym * w + t.xm];
+    const float tb = S[t.yp * w + t.xp] - S[t.yp * w + t.xm];
+    return wnorm * tc + norm * (ta + tb);
+}
+__device__ __forceinline__ float ddy(const float* __restrict__ S, int w, int x, int y, const Tap3& t, float norm,
+                                     float wnorm) {
+    const float ta = wnorm * S[t.ym * w + x] + norm * (S[t.ym * w + t.xm] + S[t.ym * w + t.xp]);
+    const float tb = wnorm * S[t.yp * w + x] + norm * (S[t.yp * w + t.xm] + S[t.yp * w + t.xp]);
+    return tb - ta;
+}
+
+// Lx and Ly of one plane (the multiscale derivatives kept for the descriptors)
+__global__ __launch_bounds__(256) void k_ak_grad(const float* __restrict__ S, float* __restrict__ Lx,
+                                                 float* __restrict__ Ly, int w, int h, int scale, float norm,
+                                                 float wnorm) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w * h) return;
     const int y = i / w, x = i - y * w;
-    float a, b;
-    if (dir == 0) {
-        a = src[y * w + reflect101(x - scale, w)];
-        b = src[y * w + reflect101(x + scale, w)];
-    } else {
-        a = src[reflect101(y - scale, h) * w + x];
-        b = src[reflect101(y + scale, h) * w + x];
-    }
-    dst[i] = deriv ? b - a : wnorm * src[i] + norm * (a + b);
+    const Tap3 t = tap3(x, y, w, h, scale);
+    Lx[i] = ddx(S, w, x, y, t, norm, wnorm);
+    Ly[i] = ddy(S, w, x, y, t, norm, wnorm);
+}
+
+// Perona-Malik g2 conductivity from the un-normalised Scharr gradient (3 10 3) of the smoothed level
+__global__ __launch_bounds__(256) void k_ak_cond(const float* __restrict__ S, int w, int h,
+                                                 const AkContrast* __restrict__ kc, int octave,
+                                                 float* __restrict__ flow) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const Tap3 t = tap3(x, y, w, h, 1);
+    const float lx = ddx(S, w, x, y, t, 3.f, 10.f), ly = ddy(S, w, x, y, t, 3.f, 10.f);
+    const float k = kc->k[octave];
+    const float inv_k = 1.0f / (k * k);
+    flow[i] = 1.0f / (1.0f + inv_k * (lx * lx + ly * ly));
+}
+
+// Hessian determinant from the first derivatives: Lxx = d/dx Lx, Lxy = d/dy Lx, Lyy = d/dy Ly
+__global__ __launch_bounds__(256) void k_ak_hessdet(const float* __restrict__ Lx, const float* __restrict__ Ly, int w,
+                                                    int h, int scale, float norm, float wnorm, float s4,
+                                                    float* __restrict__ Ldet) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    const int y = i / w, x = i - y * w;
+    const Tap3 t = tap3(x, y, w, h, scale);
+    const float lxx = ddx(Lx, w, x, y, t, norm, wnorm);
+    const float lxy = ddy(Lx, w, x, y, t, norm, wnorm);
+    const float lyy = ddy(Ly, w, x, y, t, norm, wnorm);
+    Ldet[i] = (lxx * lyy - lxy * lxy) * s4;
 }
 
 // compute_kcontrast, step 1: the largest gradient magnitude of the interior (floats >= 0 order like their bits)
 __global__ __launch_bounds__(256) void k_ak_hmax(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h,
                                                  AkContrast* __restrict__ kc) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[4];
     float v = 0.f;
-    if (i < w * h) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
         const int y = i / w, x = i - y * w;
-        if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) v = sqrtf(Lx[i] * Lx[i] + Ly[i] * Ly[i]);
+        if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) v = fmaxf(v, sqrtf(Lx[i] * Lx[i] + Ly[i] * Ly[i]));
     }
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(&kc->hmax_bits, __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (v > 0.f) atomicMax(&kc->hmax_bits, __float_as_uint(v));
+    }
 }
 
 // step 2: histogram of the magnitudes scaled to [0, nbins - 1] (integer counts: any order gives the same table)
@@ -106,8 +161,7 @@ __global__ __launch_bounds__(256) void k_ak_hist(const float* __restrict__ Lx, c
     const float hmax = __uint_as_float(kc->hmax_bits);
     if (hmax == 0.0f) return;  // uniform: every thread of the grid
     const float sc = (float)(nbins - 1) / hmax;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < w * h) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
         const int y = i / w, x = i - y * w;
         if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
             const float d = sqrtf(Lx[i] * Lx[i] + Ly[i] * Ly[i]);
@@ -139,17 +193,6 @@ __global__ void k_ak_kcontrast(int total, float perc, int nbins, int n_octaves, 
         kc->k[o] = k;
         k *= 0.75f;
     }
-}
-
-// pm_g2 conductivity
-__global__ __launch_bounds__(256) void k_ak_pm_g2(const float* __restrict__ Lx, const float* __restrict__ Ly, int n,
-                                                  const AkContrast* __restrict__ kc, int octave,
-                                                  float* __restrict__ flow) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float k = kc->k[octave];
-    const float inv_k = 1.0f / (k * k);
-    flow[i] = 1.0f / (1.0f + inv_k * (Lx[i] * Lx[i] + Ly[i] * Ly[i]));
 }
 
 // one explicit diffusion step: out = Lt + step * div(c grad Lt), zero-flux borders
@@ -187,27 +230,28 @@ __global__ __launch_bounds__(256) void k_ak_area(const float* __restrict__ src, 
     dst[i] = sum;
 }
 
-__global__ __launch_bounds__(256) void k_ak_det(const float* __restrict__ Lxx, const float* __restrict__ Lyy,
-                                                const float* __restrict__ Lxy, int n, float s4,
-                                                float* __restrict__ Ldet) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Ldet[i] = (Lxx[i] * Lyy[i] - Lxy[i] * Lxy[i]) * s4;
-}
-
-// 3 x 3 strict maxima above the threshold, inside the level's border
+// 3 x 3 strict maxima above the threshold, inside the level's border: appended (in any order; the host sorts by
+// position) with the nine determinants the sub-pixel fit needs
 __global__ __launch_bounds__(256) void k_ak_extrema(const float* __restrict__ L, int w, int h, int border, float thr,
-                                                    uint8_t* __restrict__ mask) {
+                                                    int level_at, AkExt* __restrict__ list,
+                                                    unsigned* __restrict__ count, unsigned cap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w * h) return;
     const int y = i / w, x = i - y * w;
-    uint8_t m = 0;
-    if (border + 1 < h && y >= border && y < h - border && x >= border && x < w - border) {
-        const float v = L[i];
-        m = v > thr && v > L[i - 1] && v > L[i + 1] && v > L[i - w - 1] && v > L[i - w] && v > L[i - w + 1] &&
-            v > L[i + w - 1] && v > L[i + w] && v > L[i + w + 1];
+    if (!(border + 1 < h && y >= border && y < h - border && x >= border && x < w - border)) return;
+    const float v = L[i];
+    if (!(v > thr)) return;
+    const float d0 = L[i - w - 1], d1 = L[i - w], d2 = L[i - w + 1], d3 = L[i - 1], d5 = L[i + 1], d6 = L[i + w - 1],
+                d7 = L[i + w], d8 = L[i + w + 1];
+    if (v > d3 && v > d5 && v > d0 && v > d1 && v > d2 && v > d6 && v > d7 && v > d8) {
+        const unsigned k = atomicAdd(count, 1u);
+        if (k < cap) {
+            AkExt e;
+            e.at = level_at + i;
+            e.d[0] = d0; e.d[1] = d1; e.d[2] = d2; e.d[3] = d3; e.d[4] = v; e.d[5] = d5; e.d[6] = d6; e.d[7] = d7; e.d[8] = d8;
+            list[k] = e;
+        }
     }
-    mask[i] = m;
 }
 
 // Compute_Main_Orientation: one wave per keypoint.  Lanes gather the 109 weighted samples; lane = window for the
@@ -353,21 +397,24 @@ void ak_launch_gauss(hipStream_t st, const float* src, float* tmp, float* dst, i
     hipLaunchKernelGGL(k_ak_gauss, grid1(w * h), dim3(256), 0, st, src, tmp, w, h, t, 0);
     hipLaunchKernelGGL(k_ak_gauss, grid1(w * h), dim3(256), 0, st, tmp, dst, w, h, t, 1);
 }
-void ak_launch_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, bool dx, int scale,
-                     float norm, float wnorm) {
-    hipLaunchKernelGGL(k_ak_deriv, grid1(w * h), dim3(256), 0, st, src, tmp, w, h, scale, norm, wnorm, 0, dx ? 1 : 0);
-    hipLaunchKernelGGL(k_ak_deriv, grid1(w * h), dim3(256), 0, st, tmp, dst, w, h, scale, norm, wnorm, 1, dx ? 0 : 1);
+void ak_launch_grad(hipStream_t st, const float* S, float* Lx, float* Ly, int w, int h, int scale, float norm,
+                    float wnorm) {
+    hipLaunchKernelGGL(k_ak_grad, grid1(w * h), dim3(256), 0, st, S, Lx, Ly, w, h, scale, norm, wnorm);
+}
+void ak_launch_cond(hipStream_t st, const float* S, int w, int h, const AkContrast* kc, int octave, float* flow) {
+    hipLaunchKernelGGL(k_ak_cond, grid1(w * h), dim3(256), 0, st, S, w, h, kc, octave, flow);
+}
+void ak_launch_hessdet(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int scale, float norm,
+                       float wnorm, float s4, float* Ldet) {
+    hipLaunchKernelGGL(k_ak_hessdet, grid1(w * h), dim3(256), 0, st, Lx, Ly, w, h, scale, norm, wnorm, s4, Ldet);
 }
 void ak_launch_kcontrast(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float perc, int nbins,
                          int n_octaves, AkContrast* kc) {
     (void)hipMemsetAsync(kc, 0, sizeof(AkContrast), st);
-    hipLaunchKernelGGL(k_ak_hmax, grid1(w * h), dim3(256), 0, st, Lx, Ly, w, h, kc);
-    hipLaunchKernelGGL(k_ak_hist, grid1(w * h), dim3(256), 0, st, Lx, Ly, w, h, nbins, kc);
+    const dim3 g(std::min((w * h + 255) / 256, 512));
+    hipLaunchKernelGGL(k_ak_hmax, g, dim3(256), 0, st, Lx, Ly, w, h, kc);
+    hipLaunchKernelGGL(k_ak_hist, g, dim3(256), 0, st, Lx, Ly, w, h, nbins, kc);
     hipLaunchKernelGGL(k_ak_kcontrast, dim3(1), dim3(64), 0, st, (w - 2) * (h - 2), perc, nbins, n_octaves, kc);
-}
-void ak_launch_pm_g2(hipStream_t st, const float* Lx, const float* Ly, int n, const AkContrast* kc, int octave,
-                     float* flow) {
-    hipLaunchKernelGGL(k_ak_pm_g2, grid1(n), dim3(256), 0, st, Lx, Ly, n, kc, octave, flow);
 }
 void ak_launch_nld(hipStream_t st, const float* Lt, const float* flow, float* out, int w, int h, float step) {
     hipLaunchKernelGGL(k_ak_nld, grid1(w * h), dim3(256), 0, st, Lt, flow, out, w, h, step);
@@ -377,11 +424,9 @@ void ak_launch_area(hipStream_t st, const float* src, int sw, float* dst, int dw
     hipLaunchKernelGGL(k_ak_area, grid1(dw * dh), dim3(256), 0, st, src, sw, dst, dw, dh, xfirst, xsi, xalpha, yfirst,
                        ysi, yalpha);
 }
-void ak_launch_det(hipStream_t st, const float* Lxx, const float* Lyy, const float* Lxy, int n, float s4, float* Ldet) {
-    hipLaunchKernelGGL(k_ak_det, grid1(n), dim3(256), 0, st, Lxx, Lyy, Lxy, n, s4, Ldet);
-}
-void ak_launch_extrema(hipStream_t st, const float* L, int w, int h, int border, float thr, uint8_t* mask) {
-    hipLaunchKernelGGL(k_ak_extrema, grid1(w * h), dim3(256), 0, st, L, w, h, border, thr, mask);
+void ak_launch_extrema(hipStream_t st, const float* L, int w, int h, int border, float thr, int level_at, AkExt* list,
+                       unsigned* count, unsigned cap) {
+    hipLaunchKernelGGL(k_ak_extrema, grid1(w * h), dim3(256), 0, st, L, w, h, border, thr, level_at, list, count, cap);
 }
 void ak_launch_describe(hipStream_t st, vo_keypoint* kps, int n, const AkLevels& lv, const float* arena,
                         const AkPair* pairs, int pattern, int chan, uint8_t* desc) {

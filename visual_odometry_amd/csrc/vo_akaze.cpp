@@ -8,13 +8,14 @@
 //   2. host    cross-level duplicate suppression and sub-pixel refinement of the few thousand extrema.  The rule is
 //              sequential by definition (a keypoint removes the FIRST weaker neighbour a scan of the adjacent level
 //              finds, and what one keypoint removes changes what the next one finds), so it runs in the order cv
-//              runs it, on the masks and determinants of all levels (12 MB, one copy)
+//              runs it, on the list of maxima the device appended (position + 3 x 3 determinants: ~0.2 MB)
 //   3. device  main orientation and the MLDB descriptor of every keypoint
 // Every float expression is evaluated in the order of the scalar CPU form (-ffp-contract=off).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
-#include "akaze_types.h"
 #include "ctx.h"
 
 namespace {
@@ -153,79 +154,106 @@ AreaAxis area_axis(int ssize, int dsize) {
     return t;
 }
 
-struct HostLevel {  // a level's mask and determinant on the host
+struct HostLevel {  // a level on the host: a dense mask (rebuilt from the device's list) and its maxima, row-major
     const AkGeom* g;
     uint8_t* mask;
-    const float* det;
+    const AkExt* ext;  // sorted by position; ext[k].at - g->at is the pixel index inside the level
+    int n;
+    int pos(int k) const { return ext[k].at - (int)g->at; }
+    float det_at(int p) const {  // determinant at a position that holds a maximum
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            if (pos(mid) < p) lo = mid + 1;
+            else hi = mid;
+        }
+        return ext[lo].d[4];
+    }
 };
 
 // first keypoint of `lv` (row-major scan of the window) within `radius` of (x, y); -1 if none
 long first_neighbor(const HostLevel& lv, int x, int y, int radius) {
     const int w = lv.g->w, h = lv.g->h;
+    const int j0 = std::max(x - radius, 0), j1 = std::min(x + radius, w);
     for (int i = std::max(y - radius, 0); i < std::min(y + radius, h); i++) {
         const uint8_t* row = lv.mask + (size_t)i * w;
-        for (int j = std::max(x - radius, 0); j < std::min(x + radius, w); j++) {
-            if (!row[j]) continue;
-            const int dx = j - x, dy = i - y;
-            if (dx * dx + dy * dy <= radius * radius) return (long)i * w + j;
+        for (int j = j0; j < j1;) {
+            if (j + 8 <= j1) {  // the masks are almost empty: eight bytes at a time
+                uint64_t v;
+                memcpy(&v, row + j, 8);
+                if (!v) {
+                    j += 8;
+                    continue;
+                }
+            }
+            if (row[j]) {
+                const int dx = j - x, dy = i - y;
+                if (dx * dx + dy * dy <= radius * radius) return (long)i * w + j;
+            }
+            j++;
         }
     }
     return -1;
 }
 
 // Find_Scale_Space_Extrema after the per-level maxima: upwards pass (a keypoint removes a weaker neighbour one
-// level down), then downwards from the top (a weaker neighbour one level up)
+// level down), then downwards from the top (a weaker neighbour one level up).  A level's list holds its maxima
+// as the device found them; an entry whose mask byte has been cleared since is skipped, which is what a scan of
+// the mask itself would do.
 void suppress_duplicates(std::vector<HostLevel>& lv) {
     for (size_t i = 1; i < lv.size(); i++) {
         const AkGeom &e = *lv[i].g, &ep = *lv[i - 1].g;
         const int dr = (int)e.ratio / (int)ep.ratio, radius = e.sigma_size * dr;
-        for (int y = 0; y < e.h; y++)
-            for (int x = 0; x < e.w; x++) {
-                if (!lv[i].mask[(size_t)y * e.w + x]) continue;
-                const long at = first_neighbor(lv[i - 1], x * dr, y * dr, radius);
-                if (at >= 0 && lv[i].det[(size_t)y * e.w + x] > lv[i - 1].det[at]) lv[i - 1].mask[at] = 0;
-            }
+        for (int k = 0; k < lv[i].n; k++) {
+            const int p = lv[i].pos(k);
+            if (!lv[i].mask[p]) continue;
+            const int y = p / e.w, x = p - y * e.w;
+            const long at = first_neighbor(lv[i - 1], x * dr, y * dr, radius);
+            if (at >= 0 && lv[i].ext[k].d[4] > lv[i - 1].det_at((int)at)) lv[i - 1].mask[at] = 0;
+        }
     }
     for (size_t i = lv.size() - 1; i-- > 0;) {
         const AkGeom &e = *lv[i].g, &en = *lv[i + 1].g;
         const int dr = (int)en.ratio / (int)e.ratio, radius = en.sigma_size;
-        for (int y = 0; y < e.h; y++)
-            for (int x = 0; x < e.w; x++) {
-                if (!lv[i].mask[(size_t)y * e.w + x]) continue;
-                const long at = first_neighbor(lv[i + 1], x / dr, y / dr, radius);
-                if (at >= 0 && lv[i].det[(size_t)y * e.w + x] > lv[i + 1].det[at]) lv[i + 1].mask[at] = 0;
-            }
+        for (int k = 0; k < lv[i].n; k++) {
+            const int p = lv[i].pos(k);
+            if (!lv[i].mask[p]) continue;
+            const int y = p / e.w, x = p - y * e.w;
+            const long at = first_neighbor(lv[i + 1], x / dr, y / dr, radius);
+            if (at >= 0 && lv[i].ext[k].d[4] > lv[i + 1].det_at((int)at)) lv[i + 1].mask[at] = 0;
+        }
     }
 }
 
-// Do_Subpixel_Refinement: quadratic fit of the determinant around every surviving maximum
+// Do_Subpixel_Refinement: quadratic fit of the determinant around every surviving maximum (d: its 3 x 3
+// neighbourhood, row-major)
 void refine(const std::vector<HostLevel>& lv, float derivative_factor, std::vector<vo_keypoint>& out) {
     for (size_t i = 0; i < lv.size(); i++) {
         const AkGeom& e = *lv[i].g;
-        const int w = e.w;
-        for (int y = 1; y < e.h - 1; y++)
-            for (int x = 1; x < w - 1; x++) {
-                if (!lv[i].mask[(size_t)y * w + x]) continue;
-                const float* c = lv[i].det + (size_t)y * w + x;
-                const float Dx = 0.5f * (c[1] - c[-1]), Dy = 0.5f * (c[w] - c[-w]);
-                const float Dxx = c[1] + c[-1] - 2.0f * c[0], Dyy = c[w] + c[-w] - 2.0f * c[0];
-                const float Dxy = 0.25f * (c[w + 1] + c[-w - 1] - c[-w + 1] - c[w - 1]);
-                const double det = (double)Dxx * Dyy - (double)Dxy * Dxy;  // 2 x 2 solve, as cv::solve does it
-                if (det == 0) continue;
-                const double inv = 1. / det;
-                const float dx = (float)(((double)-Dx * Dyy - (double)-Dy * Dxy) * inv);
-                const float dy = (float)(((double)-Dy * Dxx - (double)-Dx * Dxy) * inv);
-                if (std::fabs(dx) > 1.0f || std::fabs(dy) > 1.0f) continue;
-                vo_keypoint kp;
-                kp.x = (float)x * e.ratio + dx * e.ratio + 0.5f * (e.ratio - 1.0f);
-                kp.y = (float)y * e.ratio + dy * e.ratio + 0.5f * (e.ratio - 1.0f);
-                kp.size = 2.0f * e.esigma * derivative_factor;
-                kp.angle = 0.f;
-                kp.response = c[0];
-                kp.octave = e.octave;
-                kp.class_id = (int)i;
-                out.push_back(kp);
-            }
+        for (int k = 0; k < lv[i].n; k++) {
+            const int p = lv[i].pos(k);
+            if (!lv[i].mask[p]) continue;
+            const int y = p / e.w, x = p - y * e.w;
+            const float* d = lv[i].ext[k].d;
+            const float Dx = 0.5f * (d[5] - d[3]), Dy = 0.5f * (d[7] - d[1]);
+            const float Dxx = d[5] + d[3] - 2.0f * d[4], Dyy = d[7] + d[1] - 2.0f * d[4];
+            const float Dxy = 0.25f * (d[8] + d[0] - d[2] - d[6]);
+            const double det = (double)Dxx * Dyy - (double)Dxy * Dxy;  // 2 x 2 solve, as cv::solve does it
+            if (det == 0) continue;
+            const double inv = 1. / det;
+            const float dx = (float)(((double)-Dx * Dyy - (double)-Dy * Dxy) * inv);
+            const float dy = (float)(((double)-Dy * Dxx - (double)-Dx * Dxy) * inv);
+            if (std::fabs(dx) > 1.0f || std::fabs(dy) > 1.0f) continue;
+            vo_keypoint kp;
+            kp.x = (float)x * e.ratio + dx * e.ratio + 0.5f * (e.ratio - 1.0f);
+            kp.y = (float)y * e.ratio + dy * e.ratio + 0.5f * (e.ratio - 1.0f);
+            kp.size = 2.0f * e.esigma * derivative_factor;
+            kp.angle = 0.f;
+            kp.response = d[4];
+            kp.octave = e.octave;
+            kp.class_id = (int)i;
+            out.push_back(kp);
+        }
     }
 }
 
@@ -257,6 +285,12 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
     *n = 0;
     VO_HIP(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    static const bool timing = getenv("VO_AKAZE_TIMING") != nullptr;  // phase times to stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = now();
     size_t total = 0;
     const std::vector<AkGeom> ev = ak_layout(w, h, *prm, &total);
     const int nl = (int)ev.size();
@@ -267,12 +301,16 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
     enum { S_LT, S_SM, S_LX, S_LY, S_DET, S_COUNT };
     const size_t floats = W_COUNT * P + S_COUNT * total;
     VO_TRY(vo_ensure(c, c->d_ak, floats * sizeof(float) + sizeof(AkContrast) + 256));
-    VO_TRY(vo_ensure(c, c->d_ak_mask, total));
+    // every maximum with its 3 x 3 neighbourhood: strict 3 x 3 maxima cannot touch, so a quarter of the pixels
+    // (plus the partial blocks at the edges) bounds their number
+    const size_t ext_cap = total / 4 + 4096;
+    VO_TRY(vo_ensure(c, c->d_ak_mask, 256 + ext_cap * sizeof(AkExt)));
     float* A = c->d_ak.as<float>();
     auto work = [&](int i) { return A + (size_t)i * P; };
     auto plane = [&](int s, int l) { return A + W_COUNT * P + (size_t)s * total + ev[(size_t)l].at; };
     AkContrast* kc = reinterpret_cast<AkContrast*>(A + floats + (64 - floats % 64) % 64);
-    uint8_t* masks = c->d_ak_mask.as<uint8_t>();
+    unsigned* d_next = c->d_ak_mask.as<unsigned>();
+    AkExt* d_ext = reinterpret_cast<AkExt*>(c->d_ak_mask.as<char>() + 256);
 
     VO_TRY(vo_xfer_begin(c));
     VO_TRY(vo_upload_image(c, c->d_img, gray, w, h, stride));
@@ -324,75 +362,152 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
     const float* d_ftab = reinterpret_cast<const float*>(c->d_ak_tab.as<char>() + foff);
     const AkPair* d_pairs = reinterpret_cast<const AkPair*>(c->d_ak_tab.as<char>() + poff);
 
-    // ---- phase 1: Create_Nonlinear_Scale_Space ----------------------------------------------------------------
-    ak_launch_cvt(st, c->d_img.as<uint8_t>(), w, h, work(W_IMG));
-    {
-        int ksize = ceil_int(2.0f * (1.0f + (prm->soffset - 0.8f) / 0.3f));
-        ksize |= 1;
-        ak_launch_gauss(st, work(W_IMG), work(W_TMP), plane(S_SM, 0), w, h, gauss_taps(ksize, prm->soffset));
-        VO_HIP(c, hipMemcpyAsync(plane(S_LT, 0), plane(S_SM, 0), P * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    const AkTaps g5 = gauss_taps(5, 1.0f);
-    {
-        // contrast factor from the gradient histogram of the lightly smoothed input (un-normalised Scharr: 3 10 3)
-        ak_launch_gauss(st, work(W_IMG), work(W_TMP), work(W_FLOW), w, h, g5);
-        ak_launch_deriv(st, work(W_FLOW), work(W_TMP), work(W_SX), w, h, true, 1, 3.f, 10.f);
-        ak_launch_deriv(st, work(W_FLOW), work(W_TMP), work(W_SY), w, h, false, 1, 3.f, 10.f);
-        ak_launch_kcontrast(st, work(W_SX), work(W_SY), w, h, prm->kcontrast_percentile, prm->kcontrast_nbins,
-                            ev.back().octave + 1, kc);
-    }
-    for (int l = 1; l < nl; l++) {
-        const AkGeom &e = ev[(size_t)l], &ep = ev[(size_t)l - 1];
-        const size_t n_px = (size_t)e.w * e.h;
-        if (e.octave > ep.octave) {
-            const TabAt& t = tabs[(size_t)l];
-            ak_launch_area(st, plane(S_LT, l - 1), ep.w, plane(S_LT, l), e.w, e.h, d_itab + t.xf, d_itab + t.xs,
-                           d_ftab + t.xa, d_itab + t.yf, d_itab + t.ys, d_ftab + t.ya);
-        } else {
-            VO_HIP(c, hipMemcpyAsync(plane(S_LT, l), plane(S_LT, l - 1), n_px * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // ---- phase 1: Create_Nonlinear_Scale_Space, Compute_Determinant_Hessian_Response, per-level maxima ------------
+    // ~300 short launches whose arguments depend only on the image size, the parameters and the workspace
+    // addresses: captured once into a hipGraph and replayed per image (VO_AKAZE_GRAPH=0: plain launches).
+    auto enqueue = [&]() -> int {
+        VO_HIP(c, hipMemsetAsync(d_next, 0, sizeof(unsigned), st));
+        ak_launch_cvt(st, c->d_img.as<uint8_t>(), w, h, work(W_IMG));
+        {
+            int ksize = ceil_int(2.0f * (1.0f + (prm->soffset - 0.8f) / 0.3f));
+            ksize |= 1;
+            ak_launch_gauss(st, work(W_IMG), work(W_TMP), plane(S_SM, 0), w, h, gauss_taps(ksize, prm->soffset));
+            VO_HIP(c, hipMemcpyAsync(plane(S_LT, 0), plane(S_SM, 0), P * sizeof(float), hipMemcpyDeviceToDevice, st));
         }
-        ak_launch_gauss(st, plane(S_LT, l), work(W_TMP), plane(S_SM, l), e.w, e.h, g5);
-        ak_launch_deriv(st, plane(S_SM, l), work(W_TMP), work(W_SX), e.w, e.h, true, 1, 3.f, 10.f);
-        ak_launch_deriv(st, plane(S_SM, l), work(W_TMP), work(W_SY), e.w, e.h, false, 1, 3.f, 10.f);
-        ak_launch_pm_g2(st, work(W_SX), work(W_SY), (int)n_px, kc, e.octave, work(W_FLOW));
-        // FED cycle on Lt, ping-pong with a work plane; the result must end in the level's own plane
-        const std::vector<float> tau = fed_steps(e.etime - ep.etime);
-        float* cur = plane(S_LT, l);
-        float* other = work(W_LTB);
-        for (size_t j = 0; j < tau.size(); j++) {
-            ak_launch_nld(st, cur, work(W_FLOW), other, e.w, e.h, tau[j] * 0.5f);
-            std::swap(cur, other);
+        const AkTaps g5 = gauss_taps(5, 1.0f);
+        {
+            // contrast factor from the gradient histogram of the lightly smoothed input (un-normalised Scharr)
+            ak_launch_gauss(st, work(W_IMG), work(W_TMP), work(W_FLOW), w, h, g5);
+            ak_launch_grad(st, work(W_FLOW), work(W_SX), work(W_SY), w, h, 1, 3.f, 10.f);
+            ak_launch_kcontrast(st, work(W_SX), work(W_SY), w, h, prm->kcontrast_percentile, prm->kcontrast_nbins,
+                                ev.back().octave + 1, kc);
         }
-        if (cur != plane(S_LT, l))
-            VO_HIP(c, hipMemcpyAsync(plane(S_LT, l), cur, n_px * sizeof(float), hipMemcpyDeviceToDevice, st));
-    }
-    // Compute_Determinant_Hessian_Response + the per-level maxima
-    for (int l = 0; l < nl; l++) {
-        const AkGeom& e = ev[(size_t)l];
-        const float w3 = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)e.sigma_size * (w3 + 2.0f)), wnorm = w3 * norm;
-        ak_launch_deriv(st, plane(S_SM, l), work(W_TMP), plane(S_LX, l), e.w, e.h, true, e.sigma_size, norm, wnorm);
-        ak_launch_deriv(st, plane(S_SM, l), work(W_TMP), plane(S_LY, l), e.w, e.h, false, e.sigma_size, norm, wnorm);
-        ak_launch_deriv(st, plane(S_LX, l), work(W_TMP), work(W_LXX), e.w, e.h, true, e.sigma_size, norm, wnorm);
-        ak_launch_deriv(st, plane(S_LX, l), work(W_TMP), work(W_LXY), e.w, e.h, false, e.sigma_size, norm, wnorm);
-        ak_launch_deriv(st, plane(S_LY, l), work(W_TMP), work(W_LYY), e.w, e.h, false, e.sigma_size, norm, wnorm);
-        const float s4 = (float)(e.sigma_size * e.sigma_size * e.sigma_size * e.sigma_size);
-        ak_launch_det(st, work(W_LXX), work(W_LYY), work(W_LXY), e.w * e.h, s4, plane(S_DET, l));
-        ak_launch_extrema(st, plane(S_DET, l), e.w, e.h, e.border, prm->threshold, masks + e.at);
+        for (int l = 1; l < nl; l++) {
+            const AkGeom &e = ev[(size_t)l], &ep = ev[(size_t)l - 1];
+            const size_t n_px = (size_t)e.w * e.h;
+            if (e.octave > ep.octave) {
+                const TabAt& t = tabs[(size_t)l];
+                ak_launch_area(st, plane(S_LT, l - 1), ep.w, plane(S_LT, l), e.w, e.h, d_itab + t.xf, d_itab + t.xs,
+                               d_ftab + t.xa, d_itab + t.yf, d_itab + t.ys, d_ftab + t.ya);
+            } else {
+                VO_HIP(c, hipMemcpyAsync(plane(S_LT, l), plane(S_LT, l - 1), n_px * sizeof(float),
+                                         hipMemcpyDeviceToDevice, st));
+            }
+            ak_launch_gauss(st, plane(S_LT, l), work(W_TMP), plane(S_SM, l), e.w, e.h, g5);
+            ak_launch_cond(st, plane(S_SM, l), e.w, e.h, kc, e.octave, work(W_FLOW));
+            // FED cycle on Lt
+            const std::vector<float> tau = fed_steps(e.etime - ep.etime);
+            {
+                // one launch per step, ping-pong with a work plane; the result must end in the level's own plane
+                float* cur = plane(S_LT, l);
+                float* other = work(W_LTB);
+                for (size_t j = 0; j < tau.size(); j++) {
+                    ak_launch_nld(st, cur, work(W_FLOW), other, e.w, e.h, tau[j] * 0.5f);
+                    std::swap(cur, other);
+                }
+                if (cur != plane(S_LT, l))
+                    VO_HIP(c, hipMemcpyAsync(plane(S_LT, l), cur, n_px * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        }
+        for (int l = 0; l < nl; l++) {
+            const AkGeom& e = ev[(size_t)l];
+            const float w3 = 10.0f / 3.0f, norm = 1.0f / (2.0f * (float)e.sigma_size * (w3 + 2.0f)), wnorm = w3 * norm;
+            ak_launch_grad(st, plane(S_SM, l), plane(S_LX, l), plane(S_LY, l), e.w, e.h, e.sigma_size, norm, wnorm);
+            const float s4 = (float)(e.sigma_size * e.sigma_size * e.sigma_size * e.sigma_size);
+            ak_launch_hessdet(st, plane(S_LX, l), plane(S_LY, l), e.w, e.h, e.sigma_size, norm, wnorm, s4, plane(S_DET, l));
+            ak_launch_extrema(st, plane(S_DET, l), e.w, e.h, e.border, prm->threshold, (int)e.at, d_ext, d_next,
+                              (unsigned)ext_cap);
+        }
+        return VO_OK;
+    };
+    static const bool use_graph = !(getenv("VO_AKAZE_GRAPH") && atoi(getenv("VO_AKAZE_GRAPH")) == 0);
+    if (use_graph) {
+        vo_ctx::AkGraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.w = w;
+        key.h = h;
+        key.prm = *prm;
+        key.arena = c->d_ak.p;
+        key.mask = c->d_ak_mask.p;
+        key.ext_cap = ext_cap;
+        key.tab = c->d_ak_tab.p;
+        key.img = c->d_img.p;
+        if (!c->ak_graph || memcmp(&key, &c->ak_key, sizeof(key)) != 0) {
+            if (c->ak_graph) {
+                (void)hipGraphExecDestroy(c->ak_graph);
+                c->ak_graph = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            VO_HIP(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue();
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != VO_OK) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            VO_HIP(c, e);
+            const hipError_t ei = hipGraphInstantiate(&c->ak_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            VO_HIP(c, ei);
+            c->ak_key = key;
+        }
+        VO_HIP(c, hipGraphLaunch(c->ak_graph, st));
+    } else {
+        VO_TRY(enqueue());
     }
     VO_TRY(vo_check_launch(c, "AKAZE scale space"));
+    const auto t_queued = now();
 
     // ---- phase 2 (host): duplicates across levels, sub-pixel positions ------------------------------------------
-    VO_TRY(vo_ensure_pinned(c, c->h_ak, total * sizeof(float) + total));
-    float* h_det = c->h_ak.as<float>();
-    uint8_t* h_mask = reinterpret_cast<uint8_t*>(h_det + total);
-    VO_HIP(c, hipMemcpyAsync(h_det, plane(S_DET, 0), total * sizeof(float), hipMemcpyDeviceToHost, st));
-    VO_HIP(c, hipMemcpyAsync(h_mask, masks, total, hipMemcpyDeviceToHost, st));
+    // the maxima come back as a list (a few thousand entries of 40 bytes), not as planes
+    VO_TRY(vo_ensure_pinned(c, c->h_ak, 256 + ext_cap * sizeof(AkExt)));
+    unsigned* h_next = c->h_ak.as<unsigned>();
+    AkExt* h_ext = reinterpret_cast<AkExt*>(c->h_ak.as<char>() + 256);
+    VO_HIP(c, hipMemcpyAsync(h_next, d_next, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     VO_TRY(vo_xfer_finish(c));
+    const size_t n_ext = *h_next;
+    if (n_ext > ext_cap) return c->fail(VO_ERR_DEVICE, "vo_akaze_detect_compute: %zu maxima exceed their bound", n_ext);
+    if (n_ext) {
+        VO_HIP(c, hipMemcpyAsync(h_ext, d_ext, n_ext * sizeof(AkExt), hipMemcpyDeviceToHost, st));
+        VO_HIP(c, hipStreamSynchronize(st));
+    }
+    const auto t_phase1 = now();
+    // the device appends in any order; cv's order is level after level, row-major: the order of `at`
+    // (sorted through 8-byte keys: moving the 40-byte records themselves costs three times as much)
+    {
+        std::vector<uint64_t> keys(n_ext);
+        for (size_t k = 0; k < n_ext; k++) keys[k] = ((uint64_t)(uint32_t)h_ext[k].at << 32) | k;
+        std::sort(keys.begin(), keys.end());
+        c->ak_ext_sorted.resize(n_ext);
+        for (size_t k = 0; k < n_ext; k++) c->ak_ext_sorted[k] = h_ext[keys[k] & 0xffffffffu];
+        h_ext = c->ak_ext_sorted.data();
+    }
+    if (c->ak_hmask.size() < total) c->ak_hmask.assign(total, 0);  // kept all zero between calls
+    uint8_t* h_mask = c->ak_hmask.data();
+    for (size_t k = 0; k < n_ext; k++) h_mask[h_ext[k].at] = 1;
     std::vector<HostLevel> hl((size_t)nl);
-    for (int l = 0; l < nl; l++) hl[(size_t)l] = {&ev[(size_t)l], h_mask + ev[(size_t)l].at, h_det + ev[(size_t)l].at};
+    {
+        size_t k = 0;
+        for (int l = 0; l < nl; l++) {
+            const size_t end = ev[(size_t)l].at + (size_t)ev[(size_t)l].w * ev[(size_t)l].h;
+            hl[(size_t)l].g = &ev[(size_t)l];
+            hl[(size_t)l].mask = h_mask + ev[(size_t)l].at;
+            hl[(size_t)l].ext = h_ext + k;
+            size_t k1 = k;
+            while (k1 < n_ext && (size_t)h_ext[k1].at < end) k1++;
+            hl[(size_t)l].n = (int)(k1 - k);
+            k = k1;
+        }
+    }
     suppress_duplicates(hl);
     std::vector<vo_keypoint> kps;
     refine(hl, prm->derivative_factor, kps);
+    c->ak_survivors.clear();
+    for (size_t k = 0; k < n_ext; k++) {
+        if (h_mask[h_ext[k].at]) c->ak_survivors.push_back(h_ext[k].at);
+        h_mask[h_ext[k].at] = 0;
+    }
+    const auto t_host = now();
     c->ak_levels = nl;
     c->ak_total = total;
     c->ak_plane0 = W_COUNT * P;
@@ -450,6 +565,10 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
     VO_HIP(c, hipMemcpyAsync(kp, c->d_ak_kp.p, nk * sizeof(vo_keypoint), hipMemcpyDeviceToHost, st));
     VO_HIP(c, hipMemcpyAsync(desc, c->d_ak_desc.p, nk * AK_DESC_BYTES, hipMemcpyDeviceToHost, st));
     VO_HIP(c, hipStreamSynchronize(st));
+    if (timing)
+        fprintf(stderr, "[vo_akaze] queue %.2f ms, scale space + copy back %.2f ms, host suppression/refinement %.2f ms, "
+                        "orientation + descriptors + copies %.2f ms (%zu keypoints)\n",
+                ms(t_start, t_queued), ms(t_queued, t_phase1), ms(t_phase1, t_host), ms(t_host, now()), nk);
     return VO_OK;
 }
 
@@ -466,8 +585,10 @@ int vo_debug_akaze_level(vo_ctx* c, int level, int which, float* out, int* lw, i
     VO_HIP(c, hipSetDevice(c->device));
     const size_t npx = (size_t)w * h;
     if (which == 5) {
-        const uint8_t* m = reinterpret_cast<const uint8_t*>(c->h_ak.as<float>() + c->ak_total) + c->ak_at[(size_t)level];
-        for (size_t i = 0; i < npx; i++) out[i] = m[i];
+        const size_t a0 = c->ak_at[(size_t)level];
+        for (size_t i = 0; i < npx; i++) out[i] = 0.f;
+        for (const int at : c->ak_survivors)
+            if ((size_t)at >= a0 && (size_t)at < a0 + npx) out[(size_t)at - a0] = 1.f;
         return VO_OK;
     }
     const float* src = c->d_ak.as<float>() + c->ak_plane0 + (size_t)which * c->ak_total + c->ak_at[(size_t)level];

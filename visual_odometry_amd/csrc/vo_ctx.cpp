@@ -190,6 +190,7 @@ void vo_ctx_destroy(vo_ctx* c) {
                      &c->d_pts4,  &c->d_fp0,    &c->d_fp1,   &c->d_cam,    &c->d_proj,
                      &c->d_tk_pyr[0], &c->d_tk_pyr[1], &c->d_tk_deriv, &c->d_pack,
                      &c->d_ak, &c->d_ak_mask, &c->d_ak_tab, &c->d_ak_kp, &c->d_ak_desc};
+    if (c->ak_graph) (void)hipGraphExecDestroy(c->ak_graph);
     for (DevBuf* b : dev)
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,

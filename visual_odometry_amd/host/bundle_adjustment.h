@@ -11,9 +11,9 @@
 //                 with getProjectionMatrix(K, [R | t]) of those key frames, and kept when, in the first
 //                 view's frame, it is nearer than 200, deeper than 10 and less than 40 off axis (:105-110).
 //
-// Deviations, stated: the reference describes key frames with AKAZE (:41); AKAZE is not built here
-// (DESIGN.md 8), so the window is described with ORB (detectComputeORB, same 61- vs 32-byte rows going into
-// the same matcher()).  The reference indexes its point list by CAMERA index where it means the list
+// Key frames are described with AKAZE as in the reference (:41, detectComputeAKAZE -> vo_akaze_detect_compute,
+// 61-byte MLDB rows into the same matcher()); `akaze = false` describes them with ORB instead (cheaper, and the
+// descriptor the rest of the accelerated path uses).  A deviation, stated: the reference indexes its point list by CAMERA index where it means the list
 // position (:90: points[cam_idx]) — out of bounds whenever a track skips key frame 0; this mirror uses the
 // position, which is what the line computes whenever it is defined.
 #ifndef VO_HOST_BUNDLE_ADJUSTMENT_H
@@ -27,7 +27,9 @@
 
 class BundleAdjustment {
 public:
-    explicit BundleAdjustment(int orb_nfeatures = 2000) : feature_detector_(orb_nfeatures) {}
+    explicit BundleAdjustment(int orb_nfeatures = 2000, bool akaze = true)
+        : feature_detector_(orb_nfeatures), use_akaze_(akaze) {}
+    int descriptorBytes() const { return use_akaze_ ? 61 : 32; }
     void init(const vo::Matd& K, size_t max_frames);  // bundle_adjustment.cpp:16-27
     void addKeyFrame(const VOFrame& frame);           // :29-61
 
@@ -47,6 +49,7 @@ private:
     void setPBAPoints();  // :64-130
 
     FeatureDetector feature_detector_;
+    bool use_akaze_ = true;
     vo::Matd K_;
     size_t max_frames_ = 4;
     int count_ = 0;

@@ -24,7 +24,7 @@ public:
     void computeORB(const VOFrame& frame, std::vector<vo::KeyPoint>* keypoints,
                     vo::Descriptors* descriptors);  // :32-42 (keypoints made from frame.points)
 
-    // AKAZE / BRISK are not on the accelerated path: they throw.
+    // AKAZE: vo_akaze_detect_compute.  BRISK is never called by the reference: it throws.
     void detectComputeAKAZE(const VOFrame& frame, std::vector<vo::KeyPoint>* keypoints, vo::Descriptors* descriptors);
     void detectComputeBRISK(const VOFrame& frame, std::vector<vo::KeyPoint>* keypoints, vo::Descriptors* descriptors);
 

@@ -197,8 +197,31 @@ void FeatureDetector::computeORB(const VOFrame& frame, std::vector<vo::KeyPoint>
     descriptors->d.resize((size_t)n * 32);
 }
 
-void FeatureDetector::detectComputeAKAZE(const VOFrame&, std::vector<vo::KeyPoint>*, vo::Descriptors*) {
-    throw vo::Error(VO_ERR_INVALID, "detectComputeAKAZE is not on the accelerated path (use detectComputeORB)");
+// akaze_->detectAndCompute(frame.image, noArray(), *keypoints, *descriptors) with cv::AKAZE::create()'s defaults
+// (feature_detector.cpp:7,43-45): MLDB rows of 61 bytes
+void FeatureDetector::detectComputeAKAZE(const VOFrame& frame, std::vector<vo::KeyPoint>* keypoints,
+                                         vo::Descriptors* descriptors) {
+    const vo::Image& im = frame.image;
+    vo_akaze_params prm;
+    vo_akaze_params_default(&prm);
+    int cap = 16384, n = 0;
+    for (;;) {
+        keypoints->resize((size_t)cap);
+        descriptors->d.resize((size_t)cap * VO_AKAZE_DESC_BYTES);
+        const int rc = vo_akaze_detect_compute(ctx_, im.px.data(), im.width, im.height, im.width, &prm,
+                                               reinterpret_cast<vo_keypoint*>(keypoints->data()),
+                                               descriptors->d.data(), cap, &n);
+        if (rc == VO_ERR_CAPACITY && n > cap) {  // *n is the true count: once more with room for it
+            cap = n;
+            continue;
+        }
+        check(ctx_, rc);
+        break;
+    }
+    keypoints->resize((size_t)n);
+    descriptors->rows = n;
+    descriptors->cols = VO_AKAZE_DESC_BYTES;
+    descriptors->d.resize((size_t)n * VO_AKAZE_DESC_BYTES);
 }
 void FeatureDetector::detectComputeBRISK(const VOFrame&, std::vector<vo::KeyPoint>*, vo::Descriptors*) {
     throw vo::Error(VO_ERR_INVALID, "detectComputeBRISK is not on the accelerated path (use detectComputeORB)");
@@ -321,7 +344,8 @@ void BundleAdjustment::addKeyFrame(const VOFrame& frame) {
     R_.push_back(frame.pose_R);
     t_.push_back(frame.pose_t);
     vo::ImageFeatures f;
-    feature_detector_.detectComputeORB(frame, &f.keypoints, &f.descriptors);  // the reference: AKAZE (see header)
+    if (use_akaze_) feature_detector_.detectComputeAKAZE(frame, &f.keypoints, &f.descriptors);  // :41
+    else feature_detector_.detectComputeORB(frame, &f.keypoints, &f.descriptors);
     f.img_idx = count_++;
     f.img_size.width = frame.image.width;
     f.img_size.height = frame.image.height;
@@ -938,9 +962,14 @@ struct vo_host_ba {
 };
 
 vo_host_ba* vo_host_ba_create(const double* K, int max_frames, int nfeatures, char* err, int err_cap) {
+    return vo_host_ba_create_ex(K, max_frames, 1, nfeatures, err, err_cap);
+}
+
+vo_host_ba* vo_host_ba_create_ex(const double* K, int max_frames, int descriptor, int orb_nfeatures, char* err,
+                                 int err_cap) {
     try {
         vo_host_ba* b = new vo_host_ba();
-        b->ba = new BundleAdjustment(nfeatures);
+        b->ba = new BundleAdjustment(orb_nfeatures, descriptor == 0);
         vo::Matd Km(3, 3);
         for (int i = 0; i < 9; i++) Km.d[i] = K[i];
         b->ba->init(Km, (size_t)max_frames);
@@ -991,9 +1020,11 @@ int vo_host_ba_features(vo_host_ba* b, int frame, vo_keypoint* kp, uint8_t* desc
     *n = (int)f.keypoints.size();
     if (*n > cap) return -1;
     if (kp) memcpy(kp, f.keypoints.data(), (size_t)*n * sizeof(vo_keypoint));
-    if (desc) memcpy(desc, f.descriptors.d.data(), (size_t)*n * 32);
+    if (desc) memcpy(desc, f.descriptors.d.data(), (size_t)*n * f.descriptors.cols);
     return 0;
 }
+
+int vo_host_ba_desc_bytes(vo_host_ba* b) { return b->ba->descriptorBytes(); }
 
 int vo_host_ba_pair(vo_host_ba* b, int pair, int* src, int* dst, vo_dmatch* matches, uint8_t* inliers, int cap,
                     int* n) {

@@ -50,6 +50,10 @@ int vo_host_create_match_matrix(const int* src, const int* dst, const int* off, 
  * setPBAPoints() leaves for an optimiser.  pose_R 3x3 / pose_t 3: camera-to-world pose of the key frame. */
 typedef struct vo_host_ba vo_host_ba;
 vo_host_ba* vo_host_ba_create(const double* K, int max_frames, int nfeatures, char* err, int err_cap);
+/* descriptor: 0 = AKAZE (what the reference's addKeyFrame uses), 1 = ORB with orb_nfeatures */
+vo_host_ba* vo_host_ba_create_ex(const double* K, int max_frames, int descriptor, int orb_nfeatures, char* err,
+                                 int err_cap);
+int vo_host_ba_desc_bytes(vo_host_ba* b);
 void vo_host_ba_destroy(vo_host_ba* b);
 int vo_host_ba_add_key_frame(vo_host_ba* b, const uint8_t* gray, int w, int h, const double* pose_R,
                              const double* pose_t, char* err, int err_cap);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvo_host.so")
 SYMBOLS = ["vo_host_vo_create", "vo_host_vo_destroy", "vo_host_vo_add_image", "vo_host_vo_state",
            "vo_host_vo_arrays", "vo_host_load_calibration", "vo_host_load_poses", "vo_host_save_poses",
-           "vo_host_remove_points", "vo_host_create_match_matrix", "vo_host_ba_create", "vo_host_ba_destroy",
+           "vo_host_remove_points", "vo_host_create_match_matrix", "vo_host_ba_create", "vo_host_ba_create_ex", "vo_host_ba_desc_bytes", "vo_host_ba_destroy",
            "vo_host_ba_add_key_frame", "vo_host_ba_counts", "vo_host_ba_features", "vo_host_ba_pair",
            "vo_host_ba_match_matrix", "vo_host_ba_points"]
 _lib = None
@@ -32,6 +32,9 @@ def lib():
         _lib.vo_host_vo_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         _lib.vo_host_ba_create.restype = C.c_void_p
         _lib.vo_host_ba_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        _lib.vo_host_ba_create_ex.restype = C.c_void_p
+        _lib.vo_host_ba_create_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        _lib.vo_host_ba_desc_bytes.argtypes = [C.c_void_p]
         _lib.vo_host_ba_destroy.argtypes = [C.c_void_p]
         _lib.vo_host_ba_destroy.restype = None
         _lib.vo_host_ba_add_key_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -195,11 +198,13 @@ class HostBundleAdjustment:
                          ("octave", "<i4"), ("class_id", "<i4")])
     DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
 
-    def __init__(self, K, max_frames=4, nfeatures=2000):
+    def __init__(self, K, max_frames=4, nfeatures=2000, descriptor="akaze"):
+        """descriptor: "akaze" (the reference's addKeyFrame) or "orb" (nfeatures applies)."""
         self.L = lib()
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
         err = C.create_string_buffer(512)
-        self.h = self.L.vo_host_ba_create(_p(K), int(max_frames), int(nfeatures), err, 512)
+        self.h = self.L.vo_host_ba_create_ex(_p(K), int(max_frames), 0 if descriptor == "akaze" else 1,
+                                             int(nfeatures), err, 512)
         if not self.h:
             raise RuntimeError("BundleAdjustment: " + err.value.decode())
 
@@ -229,7 +234,7 @@ class HostBundleAdjustment:
 
     def features(self, frame, cap=32768):
         kp = np.zeros(cap, self.KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
+        desc = np.zeros((cap, self.L.vo_host_ba_desc_bytes(self.h)), np.uint8)
         n = C.c_int(0)
         assert self.L.vo_host_ba_features(self.h, int(frame), _p(kp), _p(desc), cap, C.byref(n)) == 0
         return kp[: n.value].copy(), desc[: n.value].copy()
