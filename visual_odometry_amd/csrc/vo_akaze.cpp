@@ -420,7 +420,8 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
         }
         return VO_OK;
     };
-    static const bool use_graph = !(getenv("VO_AKAZE_GRAPH") && atoi(getenv("VO_AKAZE_GRAPH")) == 0);
+    const char* env_graph = getenv("VO_AKAZE_GRAPH");  // read per call: a test switches it inside one process
+    const bool use_graph = !(env_graph && atoi(env_graph) == 0);
     if (use_graph) {
         vo_ctx::AkGraphKey key;
         memset(&key, 0, sizeof(key));
