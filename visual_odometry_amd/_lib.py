@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+# VO_HIP_LIB: another build of the same library (instrumented variants under tools/micro/)
+LIB_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(_HERE, "libvo_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/vo_hip.h declares

@@ -214,6 +214,22 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 #define SM_H (FT_H + 2)
 #define PX_W (FT_W + 8)
 #define PX_H (FT_H + 8)
+// tools/micro/fast_phases.sh builds variants that stop after phase n (-DVO_FAST_STOP=n) to count the
+// instructions of each phase; the library itself compiles the hook to nothing
+#ifdef VO_FAST_STOP
+#define VO_FAST_PHASE_END(n)                                                                      \
+    if (VO_FAST_STOP == (n)) {                                                                    \
+        unsigned acc_ = cntA[tid & 3] + cntB[tid & 3];  /* keep the phases' results alive */      \
+        for (int i_ = tid; i_ < 4 * FT_LCAP; i_ += 256) acc_ += listA[i_] + listB[i_];           \
+        acc_ += sm[tid % SM_H][tid % SM_W];                                                       \
+        if (acc_ == 0x12345678u) rowmask[0][0] = 1;                                               \
+        __syncthreads();                                                                          \
+        phase_e();                                                                                \
+        return;                                                                                   \
+    }
+#else
+#define VO_FAST_PHASE_END(n)
+#endif
 #define FT_LCAP 704  // >= 9 rows x 64 + 68 pixels of phase A per wave, >= 11 x 64 candidates of phase B
 
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
@@ -268,6 +284,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     }
     if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
     __syncthreads();
+    // phase E: one 64-bit mask per tile row -> global mask table
+    auto phase_e = [&]() {
+        if (tid < FT_H) {
+            const int yr = tiy * FT_H + tid;  // row inside the detector region
+            if (yr < L.rh)
+                masks[(size_t)f * g->segs_total + L.seg0 + (size_t)yr * L.segs + tix] =
+                    (unsigned long long)rowmask[tid][0] | ((unsigned long long)rowmask[tid][1] << 32);
+        }
+    };
+    VO_FAST_PHASE_END(0);
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
 
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         if (lane == 0) cntA[wv] = nloc;
     }
     __syncthreads();
+    VO_FAST_PHASE_END(1);
 
     // phase B: full arc test on the survivors, dense lanes over the four lists
     {
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         if (lane == 0) cntB[wv] = nloc;
     }
     __syncthreads();
+    VO_FAST_PHASE_END(2);
     const int b0 = cntB[0], b1 = b0 + cntB[1], b2 = b1 + cntB[2], nb = b2 + cntB[3];
     auto cornerAt = [&](int i) {
         const int seg = (i >= b0) + (i >= b1) + (i >= b2);
@@ -384,6 +412,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         sm[sy][sx] = (uint8_t)best;  // (best - 1) + 1
     }
     __syncthreads();
+    VO_FAST_PHASE_END(3);
 
     // phase D: NMS + border filter on the corners inside the tile
     const int b = max(border, 3);
@@ -415,13 +444,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     }
     __syncthreads();
 
-    // phase E
-    if (tid < FT_H) {
-        const int yr = tiy * FT_H + tid;  // row inside the detector region
-        if (yr < L.rh)
-            masks[(size_t)f * g->segs_total + L.seg0 + (size_t)yr * L.segs + tix] =
-                (unsigned long long)rowmask[tid][0] | ((unsigned long long)rowmask[tid][1] << 32);
-    }
+    phase_e();
 }
 
 // ---------------------------------------------------------------------------------------------
