@@ -466,6 +466,18 @@ def main():
                           "frac_of_valu_bound": 8192 * 8192 / avg / 1e12 / ceiling,
                           "compulsory_bytes": compulsory_bytes(8192, 8192)}
 
+        # ---- side measurement of a row next to the path: key-frame AKAZE ----------------------
+        side = None
+        if not args.no_8k:
+            ts = []
+            for f in frames[:6]:
+                t0 = time.perf_counter()
+                ka, _ = ctx.akaze_detect_compute(f)
+                ts.append(time.perf_counter() - t0)
+            side = {"akaze_ms_per_frame": float(np.median(ts[1:])) * 1e3, "akaze_keypoints": int(len(ka)),
+                    "note": "vo_akaze_detect_compute on one 1241x376 frame, host pointers in and out (key-frame "
+                            "operation of the BA front end, not part of `value`)"}
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(frames, K, args.nfeatures, args.max_iters)
@@ -502,6 +514,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
+            "side": side,
             "detector_roofline": detector,
             "pcie_inclusive": pcie,
             "lpt_imbalance": imbalance,
