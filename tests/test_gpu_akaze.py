@@ -111,3 +111,30 @@ def test_akaze_descriptors_match_across_frames(vo):
     p0 = np.stack([k0["x"], k0["y"]], 1)[ratio_ok]
     p1 = np.stack([k1["x"], k1["y"]], 1)[knn[:, 0]["trainIdx"][ratio_ok]]
     assert np.median(np.linalg.norm(p0 - p1, axis=1)) < 30  # forward motion: a few pixels of flow
+
+
+def test_akaze_strided_input_and_bad_arguments(vo):
+    """Rows with padding (stride > width) give the result of the tight image; bad arguments are refused with
+    VO_ERR_INVALID and leave the context usable."""
+    import ctypes as C
+
+    from visual_odometry_amd.api import KP_DTYPE, _p
+
+    im = load("000001")[:200, :640]
+    tight = np.ascontiguousarray(im)
+    padded = np.zeros((200, 704), np.uint8)
+    padded[:, :640] = tight
+    k0, d0 = vo.akaze_detect_compute(tight)
+    prm = api.akaze_params()
+    kp = np.zeros(8192, KP_DTYPE)
+    desc = np.zeros((8192, 61), np.uint8)
+    n = C.c_int(0)
+    rc = vo.L.vo_akaze_detect_compute(vo.h, _p(padded), 640, 200, 704, C.byref(prm), _p(kp), _p(desc), 8192, C.byref(n))
+    assert rc == 0 and n.value == len(k0)
+    assert np.array_equal(kp[: n.value], k0) and np.array_equal(desc[: n.value], d0)
+    for args in ((None, 640, 200, 704), (_p(padded), 8, 200, 704), (_p(padded), 640, 200, 600)):
+        rc = vo.L.vo_akaze_detect_compute(vo.h, args[0], args[1], args[2], args[3], C.byref(prm), _p(kp), _p(desc),
+                                          8192, C.byref(n))
+        assert rc == 1, rc  # VO_ERR_INVALID
+    k1, d1 = vo.akaze_detect_compute(tight)
+    assert np.array_equal(k1, k0) and np.array_equal(d1, d0)
