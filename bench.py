@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the frames-in-pinned-host-memory side measurement")
+    ap.add_argument("--workload", choices=["auto", "configs4"], default="auto",
+                    help="auto: configs[3] on one GPU, configs[4] on several; configs4: the 22 sequences also at N = 1")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: launch, sharding, barriers and the trajectory gather only (CPU plumbing test)")
     args = ap.parse_args()
@@ -245,7 +247,8 @@ def main():
     from visual_odometry_amd import shard, synth
 
     # ---- which sequences this rank runs ---------------------------------------------------------------
-    if world == 1:
+    multi = world > 1 or args.workload == "configs4"
+    if not multi:
         my_seqs = [(0, args.frames)]
         lengths = [args.frames]
         imbalance = 1.0
@@ -333,7 +336,11 @@ def main():
                        outputs=(out_m[: n - 1], out_im[: n - 1], out_pm[: n - 1]))
 
     def step():
-        return [run_seq(d_seq.data_ptr(), n) for _, n in my_seqs]
+        if len(my_seqs) == 1:
+            return [run_seq(d_seq.data_ptr(), my_seqs[0][1])]
+        # a rank's sequences go through one pipeline: the chunks of the next sequence follow without a drain
+        return seq.run_multi([(d_seq.data_ptr(), n) for _, n in my_seqs], w, h, w, w * h, K, params,
+                             outputs=[(out_m[: n - 1], out_im[: n - 1], out_pm[: n - 1]) for _, n in my_seqs])
 
     for _ in range(args.warmup):
         res = step()
@@ -482,7 +489,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(frames, K, args.nfeatures, args.max_iters)
 
-        if world == 1:
+        if not multi:
             workload = ("configs[3]: one seq-00-shaped sequence of %d synthetic 1241x376 frames resident in HBM "
                         "(cut back and forth from %d rendered frames), ORB nfeatures=%d + BF-Hamming knn2/ratio/gate + "
                         "5-pt RANSAC + recoverPose per consecutive pair; chunks of %d pairs on %d HIP streams; per-pair "

@@ -260,6 +260,14 @@ int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w
                   size_t frame_stride, const double* K, const vo_pair_params* params, vo_pair_result* results,
                   const vo_seq_outputs* out);
 
+/* Several sequences through the same pipeline in one call: the chunks of sequence i + 1 follow those of sequence i
+ * without draining the streams in between (a rank that owns several KITTI sequences, BASELINE configs[4]; the
+ * reference runs one sequence per process, src/main.cpp:59-66, so this has no counterpart there).  Same results
+ * as n_seq calls of vo_seq_run_ex.  results[i]: n_frames[i] - 1 entries; outs: NULL or n_seq entries. */
+int vo_seq_run_multi(vo_seq* s, const uint8_t* const* frames, const int* n_frames, int n_seq, int mem, int w, int h,
+                     int stride, size_t frame_stride, const double* K, const vo_pair_params* params,
+                     vo_pair_result* const* results, const vo_seq_outputs* outs);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------
  * When enabled, launches of the matcher kernel are bracketed with HIP events on the ctx stream;
  * vo_prof_get returns the number of launches and their summed duration since the last reset. */

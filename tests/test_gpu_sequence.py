@@ -196,3 +196,41 @@ def test_seq_full_length_sequence_configs3(oracle):
         Eg = np.array(r.E).reshape(3, 3)
         assert min(np.abs(Eg - o["E"]).max(), np.abs(Eg + o["E"]).max()) < 1e-6
         assert np.abs(np.array(r.R).reshape(3, 3) - o["R"]).max() < 1e-6 and np.abs(np.array(r.t) - o["t"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_seq_run_multi_equals_separate_runs():
+    """vo_seq_run_multi pipelines the chunks of several sequences back to back: every result, match table and
+    mask equals what one vo_seq_run_ex per sequence returns (device-resident and pinned-host frames)."""
+    import torch
+
+    from visual_odometry_amd import api, synth
+
+    K = synth.KITTI_K.copy()
+    K[0, 2], K[1, 2] = 320.0, 96.0
+    frames, _, _ = synth.make_sequence(11, 23, w=640, h=192, K=K)
+    lens = [23, 5, 2, 14]          # incl. a one-pair sequence and lengths that are not multiples of the chunk
+    starts = [0, 3, 9, 7]
+    d = torch.from_numpy(frames).cuda()
+    pinned = torch.from_numpy(frames).pin_memory()
+    n, h, w = frames.shape
+    prm = api.pair_params(500)
+    seq = api.VoSequence(0, n_streams=3, pairs_per_chunk=4)
+    cap = 700
+    for base, mem in ((d.data_ptr(), api.MEM_DEVICE), (pinned.data_ptr(), api.MEM_HOST_PINNED)):
+        single = []
+        for s0, ln in zip(starts, lens):
+            o = tuple(np.zeros((ln - 1, cap), t) for t in (api.DM_DTYPE, np.uint8, np.uint8))
+            r = seq.run(base + s0 * w * h, ln, w, h, w, w * h, K, prm, mem=mem, outputs=o)
+            single.append((r, o))
+        outs = [tuple(np.zeros((ln - 1, cap), t) for t in (api.DM_DTYPE, np.uint8, np.uint8)) for ln in lens]
+        multi = seq.run_multi([(base + s0 * w * h, ln) for s0, ln in zip(starts, lens)], w, h, w, w * h, K, prm,
+                              mem=mem, outputs=outs)
+        for (r1, o1), r2, o2, ln in zip(single, multi, outs, lens):
+            for p in range(ln - 1):
+                for f in ("n_kp0", "n_kp1", "n_good", "n_inliers", "n_pose", "status"):
+                    assert getattr(r1[p], f) == getattr(r2[p], f), (p, f)
+                assert list(r1[p].E) == list(r2[p].E) and list(r1[p].R) == list(r2[p].R) and list(r1[p].t) == list(r2[p].t)
+            for a, b in zip(o1, o2):
+                assert np.array_equal(a, b)
+    seq.close()

@@ -20,7 +20,7 @@ SYMBOLS = [
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
     "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
     "vo_lk_params_default", "vo_lk_track", "vo_debug_read_lk_level",
-    "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_run_ex", "vo_seq_get_stats",
+    "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_run_ex", "vo_seq_run_multi", "vo_seq_get_stats",
 ]
 
 

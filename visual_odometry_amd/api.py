@@ -416,6 +416,29 @@ class VoSequence:
         self.L.vo_seq_get_stats(self.h, C.byref(n), C.byref(a), C.byref(b))
         return n.value, a.value, b.value
 
+    def run_multi(self, seqs, w, h, stride, frame_stride, K, params, mem=MEM_DEVICE, outputs=None):
+        """seqs: list of (address, n_frames); outputs: None or a list of (matches, inlier_mask, pose_mask) per
+        sequence. Returns the list of result arrays. One pipeline over all chunks of all sequences."""
+        n = len(seqs)
+        K = np.ascontiguousarray(K, np.float64)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p, _ in seqs])
+        counts = (C.c_int * n)(*[int(k) for _, k in seqs])
+        res = [(PairResult * max(k - 1, 1))() for _, k in seqs]
+        resp = (C.c_void_p * n)(*[C.cast(r, C.c_void_p) for r in res])
+        outs = None
+        if outputs is not None:
+            outs = (SeqOutputs * n)()
+            for i, (m, im, pm) in enumerate(outputs):
+                cap = next(a.shape[1] for a in (m, im, pm) if a is not None)
+                for a in (m, im, pm):
+                    assert a is None or (a.flags.c_contiguous and a.shape == (seqs[i][1] - 1, cap))
+                outs[i] = SeqOutputs(_p(m), _p(im), _p(pm), cap, 0)
+        rc = self.L.vo_seq_run_multi(self.h, ptrs, counts, n, int(mem), int(w), int(h), int(stride),
+                                     C.c_size_t(frame_stride), _p(K), C.byref(params), resp, outs)
+        if rc != 0:
+            raise VoError(rc, self.L.vo_seq_last_error(self.h).decode())
+        return res
+
     def run(self, frames, n_frames, w, h, stride, frame_stride, K, params, mem=MEM_DEVICE, outputs=None):
         """frames: integer address (device or pinned host) or a uint8 numpy array (pageable host).
         outputs: optional (matches (n-1, cap) DM_DTYPE, inlier_mask (n-1, cap) uint8, pose_mask (n-1, cap) uint8)

@@ -288,20 +288,24 @@ int vo_seq_run(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, i
     return vo_seq_run_ex(s, frames, mem, n_frames, w, h, stride, frame_stride, K, prm, results, nullptr);
 }
 
-int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
-                  size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results,
-                  const vo_seq_outputs* out) {
-    if (!s) return VO_ERR_INVALID;
-    if (out && (out->match_cap <= 0 || (!out->matches && !out->inlier_mask && !out->pose_mask))) out = nullptr;
-    const bool details = out != nullptr;
-    if (!frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
-        !prm || !results || (mem != VO_MEM_HOST && mem != VO_MEM_DEVICE && mem != VO_MEM_HOST_PINNED))
-        return s->fail(VO_ERR_INVALID, "vo_seq_run: bad argument");
-    if (hipSetDevice(s->device) != hipSuccess) return s->fail(VO_ERR_DEVICE, "hipSetDevice(%d) failed", s->device);
+}  // extern "C"
+
+namespace {
+// One chunk of frame pairs of some sequence: what the runner queues, uploads and collects.
+struct ChunkDesc {
+    const uint8_t* src;         // first frame of the chunk
+    int nf;                     // frames (pairs + 1)
+    vo_pair_result* res;        // results of its first pair
+    const vo_seq_outputs* out;  // per-pair tables of its sequence (NULL: none) ...
+    size_t pair0;               // ... and the row of its first pair in them
+};
+
+// The pipeline over a list of chunks: chunk k on context k mod S, at most S in flight, results collected in
+// order.  Chunks of different sequences follow each other without draining the pipeline.
+int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, int h, int stride, size_t frame_stride,
+                   const double* K, const vo_pair_params* prm) {
     const int S = (int)s->ctx.size(), B = s->chunk_pairs;
-    const int npairs = n_frames - 1;
-    const int nchunks = (npairs + B - 1) / B;
-    auto first_of = [&](int chunk) { return std::min(chunk * B, npairs); };  // first pair (= first frame) of a chunk
+    const int nchunks = (int)ch.size();
     const size_t img = (size_t)w * h;
     int rc = VO_OK;
     int collected = 0;  // chunks [0, collected) have their results
@@ -312,7 +316,7 @@ int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w
     for (auto& P : s->pre) P.chunk[0] = P.chunk[1] = -1;  // nothing of this run is on the device yet
     auto collect = [&](int k) {
         const auto t0 = clk::now();
-        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], results + (size_t)k * B, out, (size_t)k * B));
+        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], ch[(size_t)k].res, ch[(size_t)k].out, ch[(size_t)k].pair0));
         s->wait_ms += ms_since(t0);
         return r;
     };
@@ -324,8 +328,9 @@ int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w
             collected = k - S + 1;
             if (rc != VO_OK) break;
         }
-        const int f0 = k * B, nf = std::min(B, npairs - f0) + 1;
-        const uint8_t* src = frames + (size_t)f0 * frame_stride;
+        const bool details = ch[(size_t)k].out != nullptr;
+        const int nf = ch[(size_t)k].nf;
+        const uint8_t* src = ch[(size_t)k].src;
         const auto t_submit = clk::now();
         struct Acc {
             vo_seq* s;
@@ -355,8 +360,7 @@ int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w
                 P.cap = pe == hipSuccess ? need : 0;
             }
             auto upload = [&](int chunk, int b) {
-                const int g0 = first_of(chunk), gn = first_of(chunk + 1) - g0 + 1;
-                hipError_t e2 = hipMemcpyAsync(P.img[b], frames + (size_t)g0 * frame_stride, (size_t)gn * img,
+                hipError_t e2 = hipMemcpyAsync(P.img[b], ch[(size_t)chunk].src, (size_t)ch[(size_t)chunk].nf * img,
                                                hipMemcpyHostToDevice, P.copy);
                 if (e2 == hipSuccess) e2 = hipEventRecord(P.ev[b], P.copy);
                 P.chunk[b] = chunk;
@@ -413,6 +417,58 @@ int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w
         }
     }
     return rc;
+}
+
+// the chunks of one sequence appended to `ch`
+void add_sequence(std::vector<ChunkDesc>& ch, int B, const uint8_t* frames, int n_frames, size_t frame_stride,
+                  vo_pair_result* results, const vo_seq_outputs* out) {
+    const int npairs = n_frames - 1;
+    for (int p0 = 0; p0 < npairs; p0 += B) {
+        ChunkDesc d;
+        d.src = frames + (size_t)p0 * frame_stride;
+        d.nf = std::min(B, npairs - p0) + 1;
+        d.res = results + p0;
+        d.out = out;
+        d.pair0 = (size_t)p0;
+        ch.push_back(d);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int vo_seq_run_ex(vo_seq* s, const uint8_t* frames, int mem, int n_frames, int w, int h, int stride,
+                  size_t frame_stride, const double* K, const vo_pair_params* prm, vo_pair_result* results,
+                  const vo_seq_outputs* out) {
+    if (!s) return VO_ERR_INVALID;
+    if (out && (out->match_cap <= 0 || (!out->matches && !out->inlier_mask && !out->pose_mask))) out = nullptr;
+    if (!frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
+        !prm || !results || (mem != VO_MEM_HOST && mem != VO_MEM_DEVICE && mem != VO_MEM_HOST_PINNED))
+        return s->fail(VO_ERR_INVALID, "vo_seq_run: bad argument");
+    if (hipSetDevice(s->device) != hipSuccess) return s->fail(VO_ERR_DEVICE, "hipSetDevice(%d) failed", s->device);
+    std::vector<ChunkDesc> ch;
+    add_sequence(ch, s->chunk_pairs, frames, n_frames, frame_stride, results, out);
+    return seq_run_chunks(s, ch, mem, w, h, stride, frame_stride, K, prm);
+}
+
+int vo_seq_run_multi(vo_seq* s, const uint8_t* const* frames, const int* n_frames, int n_seq, int mem, int w, int h,
+                     int stride, size_t frame_stride, const double* K, const vo_pair_params* prm,
+                     vo_pair_result* const* results, const vo_seq_outputs* outs) {
+    if (!s) return VO_ERR_INVALID;
+    if (!frames || !n_frames || n_seq < 1 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
+        !prm || !results || (mem != VO_MEM_HOST && mem != VO_MEM_DEVICE && mem != VO_MEM_HOST_PINNED))
+        return s->fail(VO_ERR_INVALID, "vo_seq_run_multi: bad argument");
+    for (int i = 0; i < n_seq; i++)
+        if (!frames[i] || n_frames[i] < 2 || !results[i])
+            return s->fail(VO_ERR_INVALID, "vo_seq_run_multi: sequence %d: bad argument", i);
+    if (hipSetDevice(s->device) != hipSuccess) return s->fail(VO_ERR_DEVICE, "hipSetDevice(%d) failed", s->device);
+    std::vector<ChunkDesc> ch;
+    for (int i = 0; i < n_seq; i++) {
+        const vo_seq_outputs* out = outs ? &outs[i] : nullptr;
+        if (out && (out->match_cap <= 0 || (!out->matches && !out->inlier_mask && !out->pose_mask))) out = nullptr;
+        add_sequence(ch, s->chunk_pairs, frames[i], n_frames[i], frame_stride, results[i], out);
+    }
+    return seq_run_chunks(s, ch, mem, w, h, stride, frame_stride, K, prm);
 }
 
 int vo_pairs_get_frame(vo_ctx* c, int frame, vo_keypoint* kp, uint8_t* desc, int cap, int* n) {
