@@ -15,6 +15,7 @@
 // k_match_filter: ratio test + displacement gate (+ optional cross-check) + order-preserving compaction.
 // Reference: src/matcher/matcher.cpp:17-38; SURVEY.md A.3.
 #include "ctx.h"
+#include <type_traits>
 
 #define KNN_IDX_MASK ((1u << VO_KEY_SHIFT) - 1u)
 #define KNN_GROUP 64  // rows whose (distance << 6 | row) keys fit 16 bits: local top-2 by 16-bit min / max
@@ -68,6 +69,25 @@ static __device__ __forceinline__ void swait(u32x16& a, u32x16& b) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), each XCD with its own L2.
+// Renumber so that the 64-query tiles of one pair share an XCD: its train rows are then fetched into one
+// L2 instead of eight (speed and traffic only; any bijection is correct).
+static __device__ __forceinline__ void knn_block(int& bx, int& by, int& bz) {
+    const int T = gridDim.x * gridDim.y, Z = gridDim.z, full = Z & ~7;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int rest;
+    if (L < full * T) {
+        bz = (L / (8 * T)) * 8 + (L & 7);
+        rest = (L % (8 * T)) >> 3;
+    } else {
+        const int g = Z - full, l2 = L - full * T;
+        bz = full + l2 % g;
+        rest = l2 / g;
+    }
+    bx = rest % (int)gridDim.x;
+    by = rest / (int)gridDim.x;
+}
+
 // W32: uint32 words per descriptor (8 or 16).  grid: x = 64-query tile, y = train split,
 // z = pair (z >= npairs: the reverse direction of pair z - npairs).
 // Per (query, row): W32 xor + W32 bcnt (the popcount instruction accumulates) + key pack + 16-bit max / min / min.
@@ -78,25 +98,8 @@ __global__ __launch_bounds__(256) void k_knn2(KnnArgs a) {
     __shared__ uint2 wres[4][64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), each XCD with its own L2.
-    // Renumber so that the 64-query tiles of one pair share an XCD: its train rows are then fetched into one
-    // L2 instead of eight (speed and traffic only; any bijection is correct).
     int bx, by, bz;
-    {
-        const int T = gridDim.x * gridDim.y, Z = gridDim.z, full = Z & ~7;
-        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        int rest;
-        if (L < full * T) {
-            bz = (L / (8 * T)) * 8 + (L & 7);
-            rest = (L % (8 * T)) >> 3;
-        } else {
-            const int g = Z - full, l2 = L - full * T;
-            bz = full + l2 % g;
-            rest = l2 / g;
-        }
-        bx = rest % (int)gridDim.x;
-        by = rest / (int)gridDim.x;
-    }
+    knn_block(bx, by, bz);
     const bool rev = bz >= a.npairs;
     const int pair = rev ? bz - a.npairs : bz;
     int nq = a.d_n ? a.d_n[pair] : a.nq;
@@ -264,6 +267,198 @@ __global__ __launch_bounds__(256) void k_knn2(KnnArgs a) {
         a.knn[(size_t)pair * a.nq_cap + qi] = out;
 }
 
+// ---- 32-byte descriptors on the matrix cores -----------------------------------------------------------
+// Hamming distance as an exact integer dot product: with train bits t_k in {0, 1} and query bits mapped to
+// s_k = 1 - 2 q_k in {+1, -1},  sum_k t_k s_k = popcount(t) - 2 <t, q>  =  hamming(q, t) - popcount(q).
+// popcount(q) is a constant of the query, so the order of a query's candidates — distance first, lower
+// train row on ties — is the order of that sum.  v_mfma_i32_32x32x32_i8 forms it for 32 train rows x 32
+// queries x 32 bit positions per instruction, 8 instructions per 256-bit tile, in integer arithmetic:
+// the result is the same number the popcount kernel produces, not an approximation of it.
+// Operand layout (lane = 32 h + c): A (train) lane holds row c, bytes j = 0..15 <-> bit 32 s + 16 h + j;
+// B (queries) lane holds query c, same bit <-> byte rule, so whatever k each byte position stands for in
+// the hardware, A and B agree.  D: lane holds query c, register g <-> train row (g & 3) + 8 (g >> 2) + 4 h.
+// So one lane sees 16 train rows of ONE query per tile: the running top two stay lane-private as in
+// k_knn2, with the query values scaled to +-64 so that the accumulator is already `value << 6` and a key is
+// one v_or with the row's position in its group of 64; keys are compared as signed 16-bit numbers.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+#define KNN_MF_NONE 0x7fffu  // no candidate: above every key (|value << 6| <= 16384)
+static __device__ __forceinline__ uint32_t min_i16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ uint32_t max_i16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// bit i of a nibble -> byte i (0 or 1)
+static __device__ __forceinline__ uint32_t spread4(uint32_t nib) { return __umul24(nib, 0x204081u) & 0x01010101u; }
+
+// Same grid, arguments and results as k_knn2<8>.  A block owns 64 queries (two 32-query operand tiles held
+// in registers by every wave), its four waves each scan a quarter of the train rows in tiles of 32.
+__global__ __launch_bounds__(256) void k_knn2_mfma(KnnArgs a) {
+    __shared__ uint2 wres[4][2][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    int bx, by, bz;
+    knn_block(bx, by, bz);
+    const bool rev = bz >= a.npairs;
+    const int pair = rev ? bz - a.npairs : bz;
+    int nq = a.d_n ? a.d_n[pair] : a.nq;
+    int nt = a.d_n ? a.d_n[pair + 1] : a.nt;
+    const uint32_t* qset = a.q + pair * a.q_stride;
+    const uint32_t* tset = a.t + pair * a.t_stride;
+    if (rev) {
+        const int n = nq;
+        nq = nt;
+        nt = n;
+        const uint32_t* s = qset;
+        qset = tset;
+        tset = s;
+    }
+    const int q0 = bx * 64;
+    if (q0 >= nq) return;
+
+    // query operands: +-64 per bit, and the query's own popcount
+    const uint32_t sh = 16u * h;
+    i32x4 B[2][8];
+    int pq[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        const uint4* Qp = reinterpret_cast<const uint4*>(qset) + (size_t)min(q0 + 32 * n + c, nq - 1) * 2;
+        const uint4 u = Qp[0], v = Qp[1];
+        const uint32_t w[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        uint32_t p = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            p += __popc(w[s]);
+            const uint32_t x = w[s] >> sh;
+#pragma unroll
+            for (int i = 0; i < 4; i++) B[n][s][i] = (int)(0x40404040u | (spread4((x >> (4 * i)) & 15u) << 7));
+        }
+        pq[n] = (int)p;
+    }
+
+    const int per_split = cdiv(nt, a.splits);
+    const int sbeg = min(nt, by * per_split), send = min(nt, sbeg + per_split);
+    const int per_wave = cdiv(send - sbeg, 4);
+    const int wbeg = __builtin_amdgcn_readfirstlane(min(send, sbeg + wave * per_wave));
+    const int wend = __builtin_amdgcn_readfirstlane(min(send, wbeg + per_wave));
+
+    uint32_t k1[2] = {VO_KEY_INVALID, VO_KEY_INVALID}, k2[2] = {VO_KEY_INVALID, VO_KEY_INVALID};
+    uint32_t l1[2] = {KNN_MF_NONE, KNN_MF_NONE}, l2[2] = {KNN_MF_NONE, KNN_MF_NONE};
+    const uint4* T4 = reinterpret_cast<const uint4*>(tset);
+    const uint32_t sh0 = sh, sh1 = sh + 4, sh2 = sh + 8, sh3 = sh + 12;
+
+    // one tile: rows r .. r + 31 (the lane's operand row is r + c), `valid` of them inside the wave's range
+    auto tile = [&](const uint4& u, const uint4& v, int jj, int valid, auto whole_tag) {
+        constexpr bool whole = decltype(whole_tag)::value;  // all 32 rows inside the wave's range
+        const uint32_t w[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        i32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            i32x4 A;
+            A[0] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh0, 4u));
+            A[1] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh1, 4u));
+            A[2] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh2, 4u));
+            A[3] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh3, 4u));
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[1][s], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int rl = (g & 3) + 8 * (g >> 2);
+            uint32_t key0 = (uint32_t)acc0[g] | (uint32_t)(jj + rl);
+            uint32_t key1 = (uint32_t)acc1[g] | (uint32_t)(jj + rl);
+            if (!whole) {
+                const bool in = rl + 4 * h < valid;
+                key0 = in ? key0 : KNN_MF_NONE;
+                key1 = in ? key1 : KNN_MF_NONE;
+            }
+            const uint32_t hi0 = max_i16(key0, l1[0]);
+            l1[0] = min_i16(key0, l1[0]);
+            l2[0] = min_i16(hi0, l2[0]);
+            const uint32_t hi1 = max_i16(key1, l1[1]);
+            l1[1] = min_i16(key1, l1[1]);
+            l2[1] = min_i16(hi1, l2[1]);
+        }
+    };
+    auto fold = [&](int gbase) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t l = j == 0 ? l1[n] : l2[n];
+                const int val = (int)(short)l >> 6;  // hamming - popcount(query)
+                const uint32_t gk = ((uint32_t)(val + pq[n]) << VO_KEY_SHIFT) | (uint32_t)(gbase + (int)(l & 63u) + 4 * h);
+                const uint32_t e = l == KNN_MF_NONE ? VO_KEY_INVALID : gk;
+                k2[n] = med3_u32(e, k1[n], k2[n]);
+                k1[n] = min(e, k1[n]);
+            }
+            l1[n] = l2[n] = KNN_MF_NONE;
+        }
+    };
+
+    int r = wbeg, gbase = wbeg, jj = 0;
+    uint4 cu = make_uint4(0, 0, 0, 0), cv = cu;
+    if (r < wend) {
+        const size_t rr = (size_t)min(r + c, wend - 1) * 2;
+        cu = T4[rr];
+        cv = T4[rr + 1];
+    }
+#pragma unroll 1
+    while (r < wend) {
+        const int rn = r + 32;
+        uint4 nu = cu, nv = cv;
+        if (rn < wend) {
+            const size_t rr = (size_t)min(rn + c, wend - 1) * 2;
+            nu = T4[rr];
+            nv = T4[rr + 1];
+        }
+        if (wend - r >= 32) tile(cu, cv, jj, 32, std::true_type());
+        else tile(cu, cv, jj, wend - r, std::false_type());
+        jj += 32;
+        if (jj == KNN_GROUP) {
+            fold(gbase);
+            gbase += KNN_GROUP;
+            jj = 0;
+        }
+        cu = nu;
+        cv = nv;
+        r = rn;
+    }
+    fold(gbase);
+
+    wres[wave][0][lane] = make_uint2(k1[0], k2[0]);
+    wres[wave][1][lane] = make_uint2(k1[1], k2[1]);
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t m1 = VO_KEY_INVALID, m2 = VO_KEY_INVALID;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const uint2 p = wres[w][h][c + 32 * hh];  // this lane's query: operand tile h, column c
+            m2 = med3_u32(p.x, m1, m2);
+            m1 = min(p.x, m1);
+            m2 = med3_u32(p.y, m1, m2);
+            m1 = min(p.y, m1);
+        }
+    }
+    const int qi = q0 + lane;
+    if (qi >= nq) return;
+    const uint2 out = make_uint2(m1, m2);
+    if (a.splits > 1)
+        a.part[((size_t)bz * a.splits + by) * a.nq_cap + qi] = out;
+    else if (rev)
+        a.rev[(size_t)pair * a.nq_cap + qi] = out;
+    else
+        a.knn[(size_t)pair * a.nq_cap + qi] = out;
+}
+
 // splits > 1 only: grid y = pair (+ npairs for the reverse direction)
 __global__ __launch_bounds__(256) void k_knn2_merge(KnnArgs a) {
     const bool rev = (int)blockIdx.y >= a.npairs;
@@ -287,7 +482,9 @@ void launch_knn2(hipStream_t st, const KnnArgs& a) {
     if (nmax <= 0 || a.npairs <= 0) return;
     const int dirs = a.cross ? 2 : 1;
     dim3 grid(cdiv(nmax, 64), a.splits, a.npairs * dirs);
-    if (a.words == 8) hipLaunchKernelGGL(k_knn2<8>, grid, dim3(256), 0, st, a);
+    static const bool mfma = !(getenv("VO_KNN_MFMA") && atoi(getenv("VO_KNN_MFMA")) == 0);
+    if (a.words == 8 && mfma) hipLaunchKernelGGL(k_knn2_mfma, grid, dim3(256), 0, st, a);
+    else if (a.words == 8) hipLaunchKernelGGL(k_knn2<8>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2<16>, grid, dim3(256), 0, st, a);
 }
 
