@@ -15,7 +15,6 @@
 // k_match_filter: ratio test + displacement gate (+ optional cross-check) + order-preserving compaction.
 // Reference: src/matcher/matcher.cpp:17-38; SURVEY.md A.3.
 #include "ctx.h"
-#include <type_traits>
 
 #define KNN_IDX_MASK ((1u << VO_KEY_SHIFT) - 1u)
 #define KNN_GROUP 64  // rows whose (distance << 6 | row) keys fit 16 bits: local top-2 by 16-bit min / max
@@ -274,27 +273,48 @@ __global__ __launch_bounds__(256) void k_knn2(KnnArgs a) {
 // train row on ties — is the order of that sum.  v_mfma_i32_32x32x32_i8 forms it for 32 train rows x 32
 // queries x 32 bit positions per instruction, 8 instructions per 256-bit tile, in integer arithmetic:
 // the result is the same number the popcount kernel produces, not an approximation of it.
-// Operand layout (lane = 32 h + c): A (train) lane holds row c, bytes j = 0..15 <-> bit 32 s + 16 h + j;
-// B (queries) lane holds query c, same bit <-> byte rule, so whatever k each byte position stands for in
-// the hardware, A and B agree.  D: lane holds query c, register g <-> train row (g & 3) + 8 (g >> 2) + 4 h.
-// So one lane sees 16 train rows of ONE query per tile: the running top two stay lane-private as in
-// k_knn2, with the query values scaled to +-64 so that the accumulator is already `value << 6` and a key is
-// one v_or with the row's position in its group of 64; keys are compared as signed 16-bit numbers.
+//
+// Operands (lane = 32 h + c).  The sum over k does not care which byte of which instruction carries which
+// bit as long as A and B agree, nor how a product of 64 is split between its factors.  So a lane takes the
+// four words 4h .. 4h+3 of its row, and word t feeds instructions 2t and 2t+1: operand dword j = 0..7 is
+//   A (train row c):   w & (0x01010101 << j)            one v_and: bytes hold 0 or 2^j   (j = 7: (w >> 1) & 0x40404040)
+//   B (query c):       +-(64 >> j) per byte, minus where the bit is set                   (j = 7: +-1)
+// every product is 0 or +-64, the accumulator is 64 * (hamming - popcount(q)) + C.
+// D: lane holds query c, register g <-> train row (g & 3) + 8 (g >> 2) + 4 h of the tile.  One lane sees 16
+// rows of ONE query per tile, so the running top two stay lane-private as in k_knn2; the C operand of the
+// first instruction is the row's position in its group of 64 rows ((g & 3) + 8 (g >> 2) + 32 * odd tile),
+// which makes the accumulator itself the 16-bit key `value << 6 | position` (signed): three 16-bit min / max
+// per candidate and nothing else.  The bit 4 h of the position is the lane's and is added when a group's two
+// keys are folded into the 32-bit (distance << 22 | row) pair.
+// The loop is software-pipelined over two accumulator sets: the 16 matrix instructions of one tile issue
+// among the selection of the previous tile's 32 x 16 candidates and the 18 v_and of the next operands.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-#define KNN_MF_NONE 0x7fffu  // no candidate: above every key (|value << 6| <= 16384)
-static __device__ __forceinline__ uint32_t min_i16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+#define KNN_MF_NONE ((short)0x7fff)  // no candidate: above every key (|value << 6| <= 16384)
+
+// operand dwords 4u .. 4u+3 of a train word
+static __device__ __forceinline__ i32x4 knn_mf_a(uint32_t w, int u) {
+    i32x4 A;
+    if (u == 0) {
+        A[0] = (int)(w & 0x01010101u);
+        A[1] = (int)(w & 0x02020202u);
+        A[2] = (int)(w & 0x04040404u);
+        A[3] = (int)(w & 0x08080808u);
+    } else {
+        A[0] = (int)(w & 0x10101010u);
+        A[1] = (int)(w & 0x20202020u);
+        A[2] = (int)(w & 0x40404040u);
+        A[3] = (int)((w >> 1) & 0x40404040u);
+    }
+    return A;
 }
-static __device__ __forceinline__ uint32_t max_i16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+// operand dword j of a query word: bytes +s where the bit is clear, -s where it is set, s = 64 >> min(j, 6)
+static __device__ __forceinline__ int knn_mf_b(uint32_t w, int j) {
+    const int p = j < 7 ? j : 6;
+    const uint32_t t = ((j < 7 ? w : w >> 1) >> p) & 0x01010101u;
+    const uint32_t s4 = (64u >> p) * 0x01010101u;
+    return (int)((s4 ^ (t * 255u)) + t);  // two's complement per byte; s >= 1, so no carry leaves a byte
 }
-// bit i of a nibble -> byte i (0 or 1)
-static __device__ __forceinline__ uint32_t spread4(uint32_t nib) { return __umul24(nib, 0x204081u) & 0x01010101u; }
 
 // Same grid, arguments and results as k_knn2<8>.  A block owns 64 queries (two 32-query operand tiles held
 // in registers by every wave), its four waves each scan a quarter of the train rows in tiles of 32.
@@ -322,78 +342,82 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(KnnArgs a) {
     const int q0 = bx * 64;
     if (q0 >= nq) return;
 
-    // query operands: +-64 per bit, and the query's own popcount
-    const uint32_t sh = 16u * h;
+    // query operands and the query's own popcount (the other half of the row is in lane ^ 32)
     i32x4 B[2][8];
     int pq[2];
 #pragma unroll
     for (int n = 0; n < 2; n++) {
-        const uint4* Qp = reinterpret_cast<const uint4*>(qset) + (size_t)min(q0 + 32 * n + c, nq - 1) * 2;
-        const uint4 u = Qp[0], v = Qp[1];
-        const uint32_t w[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-        uint32_t p = 0;
+        const uint4 u = reinterpret_cast<const uint4*>(qset)[(size_t)min(q0 + 32 * n + c, nq - 1) * 2 + h];
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        int p = 0;
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            p += __popc(w[s]);
-            const uint32_t x = w[s] >> sh;
+        for (int t = 0; t < 4; t++) {
+            p += __popc(w[t]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) B[n][s][i] = (int)(0x40404040u | (spread4((x >> (4 * i)) & 15u) << 7));
+            for (int j = 0; j < 8; j++) B[n][2 * t + (j >> 2)][j & 3] = knn_mf_b(w[t], j);
         }
-        pq[n] = (int)p;
+        pq[n] = p + __shfl_xor(p, 32);
     }
 
+    // rows of this split, then of this wave (whole groups of 64 rows for all waves but the last)
     const int per_split = cdiv(nt, a.splits);
     const int sbeg = min(nt, by * per_split), send = min(nt, sbeg + per_split);
-    const int per_wave = cdiv(send - sbeg, 4);
+    const int per_wave = (cdiv(send - sbeg, 4) + KNN_GROUP - 1) & ~(KNN_GROUP - 1);
     const int wbeg = __builtin_amdgcn_readfirstlane(min(send, sbeg + wave * per_wave));
     const int wend = __builtin_amdgcn_readfirstlane(min(send, wbeg + per_wave));
 
     uint32_t k1[2] = {VO_KEY_INVALID, VO_KEY_INVALID}, k2[2] = {VO_KEY_INVALID, VO_KEY_INVALID};
-    uint32_t l1[2] = {KNN_MF_NONE, KNN_MF_NONE}, l2[2] = {KNN_MF_NONE, KNN_MF_NONE};
+    short l1[2] = {KNN_MF_NONE, KNN_MF_NONE}, l2[2] = {KNN_MF_NONE, KNN_MF_NONE};
+    i32x16 C0, C1;  // positions of the 16 rows a lane sees in the even / odd tile of a group (without 4 h)
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        C0[g] = (g & 3) + 8 * (g >> 2);
+        C1[g] = C0[g] + 32;
+    }
+    // keep the constants in registers: as immediates they would be sixteen v_mov per tile
+    asm volatile("" : "+v"(C0), "+v"(C1));
     const uint4* T4 = reinterpret_cast<const uint4*>(tset);
-    const uint32_t sh0 = sh, sh1 = sh + 4, sh2 = sh + 8, sh3 = sh + 12;
 
-    // one tile: rows r .. r + 31 (the lane's operand row is r + c), `valid` of them inside the wave's range
-    auto tile = [&](const uint4& u, const uint4& v, int jj, int valid, auto whole_tag) {
-        constexpr bool whole = decltype(whole_tag)::value;  // all 32 rows inside the wave's range
-        const uint32_t w[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-        i32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+    auto chain = [&](const uint4& rw, const i32x16& cinit, i32x16& a0, i32x16& a1) {
+        const uint32_t w[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            i32x4 A;
-            A[0] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh0, 4u));
-            A[1] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh1, 4u));
-            A[2] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh2, 4u));
-            A[3] = (int)spread4(__builtin_amdgcn_ubfe(w[s], sh3, 4u));
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[0][s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[1][s], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int rl = (g & 3) + 8 * (g >> 2);
-            uint32_t key0 = (uint32_t)acc0[g] | (uint32_t)(jj + rl);
-            uint32_t key1 = (uint32_t)acc1[g] | (uint32_t)(jj + rl);
-            if (!whole) {
-                const bool in = rl + 4 * h < valid;
-                key0 = in ? key0 : KNN_MF_NONE;
-                key1 = in ? key1 : KNN_MF_NONE;
-            }
-            const uint32_t hi0 = max_i16(key0, l1[0]);
-            l1[0] = min_i16(key0, l1[0]);
-            l2[0] = min_i16(hi0, l2[0]);
-            const uint32_t hi1 = max_i16(key1, l1[1]);
-            l1[1] = min_i16(key1, l1[1]);
-            l2[1] = min_i16(hi1, l2[1]);
+            const i32x4 A = knn_mf_a(w[s >> 1], s & 1);
+            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[0][s], s == 0 ? cinit : a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B[1][s], s == 0 ? cinit : a1, 0, 0, 0);
         }
     };
+    auto take = [&](int n, short key) {
+        const short hi = key > l1[n] ? key : l1[n];
+        l1[n] = key < l1[n] ? key : l1[n];
+        l2[n] = hi < l2[n] ? hi : l2[n];
+    };
+    auto select = [&](const i32x16& a0, const i32x16& a1) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            take(0, (short)a0[g]);
+            take(1, (short)a1[g]);
+        }
+    };
+    // rows beyond `valid` (the tile's last rows past the wave's range) do not compete
+    auto select_masked = [&](const i32x16& a0, const i32x16& a1, int valid) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const bool in = (g & 3) + 8 * (g >> 2) + 4 * h < valid;
+            take(0, in ? (short)a0[g] : KNN_MF_NONE);
+            take(1, in ? (short)a1[g] : KNN_MF_NONE);
+        }
+    };
+    // fold the group's two keys of either query into the global pairs and start a new group
     auto fold = [&](int gbase) {
 #pragma unroll
         for (int n = 0; n < 2; n++) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const uint32_t l = j == 0 ? l1[n] : l2[n];
-                const int val = (int)(short)l >> 6;  // hamming - popcount(query)
-                const uint32_t gk = ((uint32_t)(val + pq[n]) << VO_KEY_SHIFT) | (uint32_t)(gbase + (int)(l & 63u) + 4 * h);
+                const short l = j == 0 ? l1[n] : l2[n];
+                const int val = (int)l >> 6;  // hamming - popcount(query)
+                const uint32_t gk =
+                    ((uint32_t)(val + pq[n]) << VO_KEY_SHIFT) | (uint32_t)(gbase + ((int)l & 63) + 4 * h);
                 const uint32_t e = l == KNN_MF_NONE ? VO_KEY_INVALID : gk;
                 k2[n] = med3_u32(e, k1[n], k2[n]);
                 k1[n] = min(e, k1[n]);
@@ -401,36 +425,46 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(KnnArgs a) {
             l1[n] = l2[n] = KNN_MF_NONE;
         }
     };
+    auto load_rows = [&](int r) { return T4[(size_t)min(r + c, wend - 1) * 2 + h]; };
 
-    int r = wbeg, gbase = wbeg, jj = 0;
-    uint4 cu = make_uint4(0, 0, 0, 0), cv = cu;
-    if (r < wend) {
-        const size_t rr = (size_t)min(r + c, wend - 1) * 2;
-        cu = T4[rr];
-        cv = T4[rr + 1];
-    }
+    int r = wbeg;
+    const int ngroups = (wend - wbeg) / KNN_GROUP;
+    if (ngroups > 0) {
+        i32x16 aE0, aE1, aO0, aO1;
+#pragma unroll
+        for (int g = 0; g < 16; g++) aO0[g] = aO1[g] = 0x7fff;  // nothing to select on the first trip
+        uint4 we = load_rows(r), wo = load_rows(r + 32);
 #pragma unroll 1
-    while (r < wend) {
-        const int rn = r + 32;
-        uint4 nu = cu, nv = cv;
-        if (rn < wend) {
-            const size_t rr = (size_t)min(rn + c, wend - 1) * 2;
-            nu = T4[rr];
-            nv = T4[rr + 1];
+        for (int g = 0; g < ngroups; g++) {
+            const int rn = min(r + KNN_GROUP, wend - KNN_GROUP);  // last trip: reload in bounds, unused
+            const uint4 ne = load_rows(rn), no = load_rows(rn + 32);
+            chain(we, C0, aE0, aE1);  // even tile of this group ...
+            select(aO0, aO1);         // ... among the selection of the previous group's odd tile
+            fold(r - KNN_GROUP);      // previous group complete (first trip: no keys, nothing changes)
+            chain(wo, C1, aO0, aO1);
+            select(aE0, aE1);
+#if !defined(KNN_MF_NOSCHED)
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix instruction
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // eight vector instructions in its shadow
+            }
+#endif
+            we = ne;
+            wo = no;
+            r += KNN_GROUP;
         }
-        if (wend - r >= 32) tile(cu, cv, jj, 32, std::true_type());
-        else tile(cu, cv, jj, wend - r, std::false_type());
-        jj += 32;
-        if (jj == KNN_GROUP) {
-            fold(gbase);
-            gbase += KNN_GROUP;
-            jj = 0;
-        }
-        cu = nu;
-        cv = nv;
-        r = rn;
+        select(aO0, aO1);
+        fold(r - KNN_GROUP);
     }
-    fold(gbase);
+    // the last rows (fewer than a group): one tile at a time
+#pragma unroll 1
+    for (; r < wend; r += 32) {
+        i32x16 a0, a1;
+        chain(load_rows(r), C0, a0, a1);
+        select_masked(a0, a1, wend - r);
+        fold(r);
+    }
 
     wres[wave][0][lane] = make_uint2(k1[0], k2[0]);
     wres[wave][1][lane] = make_uint2(k1[1], k2[1]);
