@@ -19,9 +19,9 @@ Frames: one `--base-frames`-frame sequence is rendered per rank (visual_odometry
 sequences are cut from it back and forth (0..B-1, B-2..1, 0..), so every consecutive pair is a pair of
 neighbouring rendered frames; every frame of the long sequence is its own 466 616 bytes in HBM.
 
-Prints ONE JSON line on rank 0.  `roofline` is the matcher kernel against its VALU issue bound (DESIGN.md
-4: nothing else bounds it, the train rows sit in SGPRs); `cpu_baseline` is the optimised CPU port
-(cpu_baseline/) on the host cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is the matcher kernel — the Hamming distances as exact int8 dot
+products on the matrix cores — against the dense int8 MFMA peak; `cpu_baseline` is the optimised
+CPU port (cpu_baseline/) on the host cores on a bounded sample.
 """
 import argparse
 import json
@@ -38,16 +38,21 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
-# VALU issue bound of the matcher row (tools/micro/valu_table.hip -> profiles/r2_valu_table.txt): cycles per
-# wave64 instruction on one SIMD; per (64 queries x 1 train row): 8 v_xor + 8 v_bcnt + 1 v_lshl_or +
-# v_max_u16 + 2 v_min_u16.
-CYC_FAST, CYC_SLOW = 2.3, 4.15
-ROW_CYCLES = 8 * CYC_FAST + 8 * CYC_SLOW + CYC_SLOW + 3 * CYC_FAST
+# Matcher on the matrix cores: one v_mfma_i32_32x32x32_i8 (32 train rows x 32 queries x 32 bit positions =
+# 32768 multiply-adds) issues every 32 cycles on each of the 1024 SIMDs (tools/micro/mfma_rate.hip; the same
+# cycles as the bf16 32x32x16 form, so twice its rate: MI355X_MICROARCH.md's ~2.5 PFLOP/s dense bf16 -> ~5 POP/s).
+# A descriptor pair is 256 multiply-adds = 512 operations.
 SIMDS, CLOCK_GHZ = 1024, 2.4
+INT8_PEAK_TOPS = SIMDS * CLOCK_GHZ * 1e9 * (32 * 32 * 32 / 32.0) * 2 / 1e12  # 5033
+OPS_PER_DESC_PAIR = 512
+# What the instruction mix allows (tools/micro/mfma_valu.hip, profiles/r2_mfma_valu.txt): beside back-to-back
+# MFMAs a SIMD spends ~17 cycles per MFMA plus ~2.8 per vector instruction past the fifth; the kernel needs
+# ~10 vector instructions per MFMA (6 of them the three 16-bit min / max per candidate).
+MIX_CYCLES_PER_MFMA = 17 + 2.8 * 10
 
 
-def valu_ceiling_tpairs():
-    return SIMDS * CLOCK_GHZ * 1e9 * 64 / ROW_CYCLES / 1e12
+def mfma_ceiling_tpairs():
+    return INT8_PEAK_TOPS / OPS_PER_DESC_PAIR
 
 
 def scan_bytes(nq, nt):
@@ -399,8 +404,9 @@ def main():
         bkp = [rb[0].n_kp0] + [rb[p].n_kp1 for p in range(nc)]
         knn_avg_s = knn_ms / max(knn_n, 1) * 1e-3
         desc_pairs = sum(bkp[p] * bkp[p + 1] for p in range(nc))
-        ceiling = valu_ceiling_tpairs()
-        achieved = desc_pairs / knn_avg_s / 1e12 if knn_avg_s > 0 else 0.0
+        ceiling = mfma_ceiling_tpairs()
+        achieved_pairs = desc_pairs / knn_avg_s / 1e12 if knn_avg_s > 0 else 0.0
+        achieved = achieved_pairs * OPS_PER_DESC_PAIR  # TOP/s
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):  # HBM bytes per launch from the committed PMC passes (tools/gpu_profile.sh)
@@ -414,11 +420,17 @@ def main():
         comp = sum(bkp[p] * 32 for p in range(nc + 1)) + sum(bkp[p] * 16 for p in range(nc))
         scan = sum(scan_bytes(bkp[p], bkp[p + 1]) for p in range(nc))
         roofline = {
-            "kernel": "k_knn2<8>", "bound": "valu", "achieved": achieved, "peak": ceiling,
-            "unit": "T descriptor pairs/s", "frac": achieved / ceiling, "traffic": traffic,
-            "peak_model": "per 64 queries x 1 train row: 8 v_xor_b32 + 3 16-bit min/max at %.2f cycles, 8 v_bcnt_u32_b32 "
-                          "+ v_lshl_or_b32 at %.2f cycles (measured issue costs, profiles/r2_valu_table.txt) = %.1f "
-                          "cycles on each of %d SIMDs at %.1f GHz" % (CYC_FAST, CYC_SLOW, ROW_CYCLES, SIMDS, CLOCK_GHZ),
+            "kernel": "k_knn2_mfma", "bound": "mfma", "achieved": achieved, "peak": INT8_PEAK_TOPS,
+            "unit": "TOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": traffic,
+            "peak_model": "dense int8 MFMA: v_mfma_i32_32x32x32_i8 (32768 multiply-adds) per 32 cycles on each of %d "
+                          "SIMDs at %.1f GHz; a descriptor pair = 256 multiply-adds = %d operations, exact integer "
+                          "arithmetic" % (SIMDS, CLOCK_GHZ, OPS_PER_DESC_PAIR),
+            "achieved_Tpairs_s": achieved_pairs, "peak_Tpairs_s": ceiling,
+            "issue_mix_bound": {"Tpairs_s": ceiling * 32.0 / MIX_CYCLES_PER_MFMA,
+                                "frac_of_it": achieved_pairs / (ceiling * 32.0 / MIX_CYCLES_PER_MFMA),
+                                "note": "what the selection costs: ~10 vector instructions per MFMA (three 16-bit "
+                                        "min / max per candidate) make a SIMD spend ~%.0f cycles per MFMA instead of 32 "
+                                        "(tools/micro/mfma_valu.hip)" % MIX_CYCLES_PER_MFMA},
             "avg_launch_us": knn_avg_s * 1e6, "pairs_per_launch": nc, "descriptor_pairs_per_launch": desc_pairs,
             "compulsory_bytes_per_launch": comp,
             "traffic_over_compulsory": traffic / comp if traffic else None,
@@ -470,7 +482,7 @@ def main():
             ctx.prof_enable(False)
             avg = kms / max(kn, 1) * 1e-3
             matcher_8k = {"avg_launch_us": avg * 1e6, "achieved_Tpairs_s": 8192 * 8192 / avg / 1e12,
-                          "frac_of_valu_bound": 8192 * 8192 / avg / 1e12 / ceiling,
+                          "frac_of_mfma_peak": 8192 * 8192 / avg / 1e12 / ceiling,
                           "compulsory_bytes": compulsory_bytes(8192, 8192)}
 
         # ---- side measurement of a row next to the path: key-frame AKAZE ----------------------

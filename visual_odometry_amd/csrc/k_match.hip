@@ -313,7 +313,7 @@ static __device__ __forceinline__ int knn_mf_b(uint32_t w, int j) {
     const int p = j < 7 ? j : 6;
     const uint32_t t = ((j < 7 ? w : w >> 1) >> p) & 0x01010101u;
     const uint32_t s4 = (64u >> p) * 0x01010101u;
-    return (int)((s4 ^ (t * 255u)) + t);  // two's complement per byte; s >= 1, so no carry leaves a byte
+    return (int)((s4 ^ ((t << 8) - t)) + t);  // two's complement per byte; s >= 1, so no carry leaves a byte
 }
 
 // Same grid, arguments and results as k_knn2<8>.  A block owns 64 queries (two 32-query operand tiles held
@@ -391,6 +391,9 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(KnnArgs a) {
         const short hi = key > l1[n] ? key : l1[n];
         l1[n] = key < l1[n] ? key : l1[n];
         l2[n] = hi < l2[n] ? hi : l2[n];
+        // two-operand 16-bit min / max issue in ~2.3 cycles, the three-operand forms the compiler would merge
+        // successive updates into (v_min3_i16) in ~8 (tools/micro/mfma_valu.hip): keep the updates apart
+        asm("" : "+v"(l1[n]), "+v"(l2[n]));
     };
     auto select = [&](const i32x16& a0, const i32x16& a1) {
 #pragma unroll
@@ -443,13 +446,11 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(KnnArgs a) {
             fold(r - KNN_GROUP);      // previous group complete (first trip: no keys, nothing changes)
             chain(wo, C1, aO0, aO1);
             select(aE0, aE1);
-#if !defined(KNN_MF_NOSCHED)
 #pragma unroll
             for (int i = 0; i < 32; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix instruction
-                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // eight vector instructions in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // its share of the vector instructions
             }
-#endif
             we = ne;
             wo = no;
             r += KNN_GROUP;
