@@ -173,3 +173,40 @@ def test_cross_check_option(vo, oracle, nq, nt):
     assert np.array_equal(got, want)
     assert 0 < len(want) <= len(plain)
     assert np.array_equal(vo.match_filter(g, gv, kq, kt, 0.9, 200.0), plain)  # default stays the reference's
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (31, 33), (64, 64), (65, 129), (500, 257), (2000, 1987), (3000, 4100)])
+def test_knn2_matrix_core_kernel_equals_popcount_kernel(vo, oracle, nq, nt, monkeypatch):
+    """32-byte rows: k_knn2_mfma (int8 dot products on the matrix cores, the default) and k_knn2<8> (xor +
+    popcount, VO_KNN_MFMA=0) are two independent formulations of the same integers; both must give the oracle's
+    table, ties included (rows drawn from 8 distinct values make most distances tie)."""
+    rng = np.random.default_rng(nq * 7919 + nt)
+    for kind in ("random", "ties"):
+        if kind == "random":
+            q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+            t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        else:
+            pool = rng.integers(0, 256, (8, 32), dtype=np.uint8)
+            q = pool[rng.integers(0, 8, nq)]
+            t = pool[rng.integers(0, 8, nt)]
+        monkeypatch.setenv("VO_KNN_MFMA", "0")
+        gp, vp = vo.knn2_hamming(q, t)
+        monkeypatch.delenv("VO_KNN_MFMA")
+        gm, vm = vo.knn2_hamming(q, t)
+        o, ov = oracle.knn2_hamming(q, t)
+        assert np.array_equal(vp, vm) and np.array_equal(vm, ov)
+        _same_knn(gm, gp)
+        _same_knn(gm, o)
+
+
+def test_knn2_matrix_core_kernel_extreme_rows(vo, oracle):
+    """All-zero and all-one rows: distances 0 and 256, the ends of the accumulator's range."""
+    q = np.zeros((70, 32), np.uint8)
+    q[1::2] = 255
+    t = np.zeros((130, 32), np.uint8)
+    t[::3] = 255
+    t[5, 0] = 1
+    g, gv = vo.knn2_hamming(q, t)
+    o, ov = oracle.knn2_hamming(q, t)
+    assert np.array_equal(gv, ov)
+    _same_knn(g, o)

@@ -18,8 +18,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WIDE_READERS = ()  # kernels whose global reads are 16 B per lane streaming loads (the matcher reads its train rows
-                    # with scalar loads now: 64-byte requests, counted as they are)
+WIDE_READERS = ("k_knn2_mfma",)  # kernels whose global reads are 16 B per lane streaming loads: the matrix-core
+                                  # matcher reads train rows and queries with global_load_dwordx4 (the popcount
+                                  # kernel read its rows with scalar loads: 64-byte requests, counted as they are)
 
 
 def short(name):

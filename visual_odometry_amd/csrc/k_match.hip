@@ -517,7 +517,10 @@ void launch_knn2(hipStream_t st, const KnnArgs& a) {
     if (nmax <= 0 || a.npairs <= 0) return;
     const int dirs = a.cross ? 2 : 1;
     dim3 grid(cdiv(nmax, 64), a.splits, a.npairs * dirs);
-    static const bool mfma = !(getenv("VO_KNN_MFMA") && atoi(getenv("VO_KNN_MFMA")) == 0);
+    // 32-byte rows go to the matrix-core kernel; VO_KNN_MFMA=0 (read per call: the tests switch it) keeps them
+    // on the popcount kernel, which 64-byte rows always use
+    const char* env = getenv("VO_KNN_MFMA");
+    const bool mfma = !(env && atoi(env) == 0);
     if (a.words == 8 && mfma) hipLaunchKernelGGL(k_knn2_mfma, grid, dim3(256), 0, st, a);
     else if (a.words == 8) hipLaunchKernelGGL(k_knn2<8>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2<16>, grid, dim3(256), 0, st, a);
