@@ -307,13 +307,17 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         auto compass = [&](int sy, int sx, bool in) {
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
             const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-            const int v = c[0], lo = v - threshold, hi = v + threshold;
-            const int r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
+            // 16-bit arithmetic: two-operand 16-bit min / max issue in 2.3 cycles, 32-bit ones in 4.15
+            // (the compiler turns the eight compares into six min / max and two compares)
+            short v = c[0], r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
+            // the five reads happen for every (sy, sx), outside any branch on the border conditions
+            pin_loaded(v), pin_loaded(r0), pin_loaded(r4), pin_loaded(r8), pin_loaded(r12);
+            const short lo = (short)(v - (short)threshold), hi = (short)(v + (short)threshold);
             const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
             const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
             // two adjacent compass points of one polarity = one of {0, 8} and one of {4, 12}
-            const bool surv = in && x >= 3 && x < w - 3 && y >= 3 && y < h - 3 &&
-                              (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12)));
+            const bool inside = in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3);
+            const bool surv = inside & (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12)));
             const unsigned long long m = __ballot(surv);
             if (m) {
                 if (surv) mine[nloc + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
