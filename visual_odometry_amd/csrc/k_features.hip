@@ -998,6 +998,24 @@ __device__ __forceinline__ int row16_sum(int v) {
     return v;
 }
 
+// Per-keypoint gather kernels, grid (blocks per frame, frames): workgroups are dealt to the 8 XCDs round-robin in
+// dispatch order (x fastest), each XCD with its own L2.  Renumbered so that the blocks of one frame run on one
+// XCD (frame f of a group of eight on XCD f & 7): a frame's pyramid (1.5 MB) then stays in that XCD's L2 while
+// its keypoints' patches are gathered, instead of every XCD fetching every frame (traffic and latency only;
+// any bijection is correct).
+static __device__ __forceinline__ void xcd_frame_block(int& bx, int& f) {
+    const int T = gridDim.x, Z = gridDim.y, full = Z & ~7;
+    const int L = blockIdx.x + T * blockIdx.y;
+    if (L < full * T) {
+        f = (L / (8 * T)) * 8 + (L & 7);
+        bx = (L % (8 * T)) >> 3;
+    } else {
+        const int g = Z - full, l2 = L - full * T;
+        f = full + l2 % g;
+        bx = l2 / g;
+    }
+}
+
 // Two keypoints per wave: lane r of a half-wave owns row v = r - 15 of the 31 x 31 patch, reads its
 // 36-byte window (nine aligned dwords) and its nine mask dwords, and takes sum(b) and sum((4k + j) b)
 // with two accumulating v_dot4_u32_u8 per dword: m10 = sum((4k + j) b) - (15 + o) sum(b), m01 = v sum(b).
@@ -1010,7 +1028,8 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
                                                   const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
     const int n = nkp[f];
     // the per-level counts and offsets travel with the keypoint count (uniform addresses, one batch of
     // scalar loads), before the early exit that only needs the count
@@ -1024,9 +1043,9 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
             ofs[i] = lo[i];
         }
     }
-    if ((int)(blockIdx.x * 8 + 2 * (threadIdx.x >> 6)) >= n) return;  // the whole wave
-    const int k = min((int)(blockIdx.x * 8 + (threadIdx.x >> 5)), n - 1);
-    const bool live = (int)(blockIdx.x * 8 + (threadIdx.x >> 5)) < n;
+    if ((int)(bx * 8 + 2 * (threadIdx.x >> 6)) >= n) return;  // the whole wave
+    const int k = min((int)(bx * 8 + (threadIdx.x >> 5)), n - 1);
+    const bool live = (int)(bx * 8 + (threadIdx.x >> 5)) < n;
     const int r = min((int)threadIdx.x & 31, 30);
     Cand cd;
     int lg;
@@ -1199,8 +1218,10 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     __shared__ uint32_t win[RB_KP][RB_ROWS * RB_DW];
     __shared__ float s_ca[RB_KP], s_sa[RB_KP];
     __shared__ PyrGeom s_g;
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int k0 = blockIdx.x * RB_KP, n = nkp[f];
+    const int tid = threadIdx.x;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int k0 = bx * RB_KP, n = nkp[f];
     if (k0 >= n) return;
     // Loads that depend on nothing else go out together: geometry, pattern, the slot's keypoint and (first
     // lanes) the angles; the window loads follow in one batch after the first barrier.
