@@ -854,7 +854,9 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
     RI* v = reinterpret_cast<RI*>(sel_smem);
     uint16_t* Lp = reinterpret_cast<uint16_t*>(v + sel_cap);
     uint16_t* Ra = Lp + sel_cap;
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    // grid (frames, levels): dispatch order is x fastest and round-robin over the 8 XCDs, so the long level-0
+    // lists go out first and are spread over all XCDs (with the level in x every level-0 list sat on XCD 0)
+    const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
     const int b = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l], max_cand);
     const int e = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l + 1], max_cand);
     int n = e - b;
@@ -1353,7 +1355,7 @@ void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom
     const size_t lds = (size_t)sel_cap * (sizeof(RI) + 2 * sizeof(uint16_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_select),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_orb_select, dim3(hg.nlevels, nframes), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
+    hipLaunchKernelGGL(k_orb_select, dim3(nframes, hg.nlevels), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
                        max_cand, quota, sel_cap, selcand, selcnt, flags);
     hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
                        n_bound, nframes);
