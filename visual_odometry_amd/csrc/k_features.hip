@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 //   phase D  NMS + border filter of the corners inside the tile -> per-row 64-bit masks in LDS,
 //            score byte of each keypoint -> sparse global score map
 //   phase E  one 64-bit mask per tile row -> global mask table
+// Phases A, B and C run per wave on the wave's own rows and lists (a wave's LDS operations complete in
+// order, so no block barrier separates them); the block meets after phase 0, before the NMS and before E.
 // Row-major keypoint order (what cv's FAST emits) is rebuilt from the masks by k_row_scan /
 // k_cand_write.
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +244,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     __shared__ uint16_t listA[4 * FT_LCAP];
     __shared__ uint16_t listB[4 * FT_LCAP];
     __shared__ uint32_t rowmask[FT_H][2];
-    __shared__ int cntA[4], cntB[4];
+    __shared__ int cntB[4];
+#ifdef VO_FAST_STOP
+    __shared__ int cntA[4];  // only the phase-counting variants read the survivor counts across waves
+#endif
     const uint8_t* px = reinterpret_cast<const uint8_t*>(px4);
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0;
@@ -297,13 +302,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
 
+    // A wave's order of LDS operations is the order of its instructions, so between a phase's writes to the
+    // wave's own list and the next phase's reads of it only the compiler has to be held back: no block barrier.
+    auto wave_lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
     // phase A: compass test.  Wave w takes the rows w, w + 4, ... of the score region with lane =
     // column; columns 64 and 65 of all rows are one more step for waves 2 and 3 (they have a row less).
     // Branch-free per row: the LDS reads are in range for every (sy, sx) of the score region, the
     // image-border conditions are folded into the survivor mask, so that mask is the ballot itself.
+    int na = 0;  // survivors of this wave (wave-uniform)
+    uint16_t* mineA = listA + wv * FT_LCAP;
     {
-        int nloc = 0;
-        uint16_t* mine = listA + wv * FT_LCAP;
         auto compass = [&](int sy, int sx, bool in) {
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
             const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
@@ -320,8 +333,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
             const bool surv = inside & (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12)));
             const unsigned long long m = __ballot(surv);
             if (m) {
-                if (surv) mine[nloc + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
-                nloc += __popcll(m);
+                if (surv) mineA[na + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
+                na += __popcll(m);
             }
         };
         for (int sy = wv; sy < SM_H; sy += 4) compass(sy, lane, true);
@@ -329,23 +342,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
             const int q = (wv - 2) * 64 + lane;  // 0 .. 2 * SM_H - 1
             compass(min(q >> 1, SM_H - 1), FT_W + (q & 1), q < 2 * SM_H);
         }
-        if (lane == 0) cntA[wv] = nloc;
     }
+    wave_lds_sync();
+#ifdef VO_FAST_STOP
+    if (lane == 0) cntA[wv] = na;
     __syncthreads();
+#endif
     VO_FAST_PHASE_END(1);
 
-    // phase B: full arc test on the survivors, dense lanes over the four lists
+    // phase B: full arc test on the wave's own survivors, dense lanes; corners go to the wave's second list
+    int nb_w = 0;  // corners of this wave (wave-uniform)
+    uint16_t* mineB = listB + wv * FT_LCAP;
     {
-        const int a0 = cntA[0], a1 = a0 + cntA[1], a2 = a1 + cntA[2], na = a2 + cntA[3];
-        int nloc = 0;
-        uint16_t* mine = listB + wv * FT_LCAP;
-        for (int i0 = 0; i0 < na; i0 += 256) {
-            const int i = i0 + tid;
+        for (int i0 = 0; i0 < na; i0 += 64) {
+            const int i = i0 + lane;
             bool corner = false;
             int p = 0;
             if (i < na) {
-                const int seg = (i >= a0) + (i >= a1) + (i >= a2);
-                p = listA[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? a0 : seg == 2 ? a1 : a2)];
+                p = mineA[i];
                 const int sy = p >> 7, sx = p & 127;
                 const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
                 const int v = c[0], lo = v - threshold, hi = v + threshold;
@@ -377,24 +391,23 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 p |= (rd & 0xffffu) ? 0x2000 : 0;
             }
             const unsigned long long m = __ballot(corner);
-            if (corner) mine[nloc + mbcnt(m)] = (uint16_t)p;
-            nloc += __popcll(m);
+            if (corner) mineB[nb_w + mbcnt(m)] = (uint16_t)p;
+            nb_w += __popcll(m);
         }
-        if (lane == 0) cntB[wv] = nloc;
+        if (lane == 0) cntB[wv] = nb_w;
     }
+    wave_lds_sync();
+#ifdef VO_FAST_STOP
     __syncthreads();
+#endif
     VO_FAST_PHASE_END(2);
-    const int b0 = cntB[0], b1 = b0 + cntB[1], b2 = b1 + cntB[2], nb = b2 + cntB[3];
-    auto cornerAt = [&](int i) {
-        const int seg = (i >= b0) + (i >= b1) + (i >= b2);
-        return (int)listB[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? b0 : seg == 2 ? b1 : b2)];
-    };
 
     // phase C: cornerScore<16> = max(threshold, max over the 16 arcs of min(d), of min(-d)) - 1 with
     // d = v - ring.  Only the polarity that has the arc can exceed the threshold (the other one would
     // need a second 9-arc), so one min network on e = +-d is enough: the same score.
-    for (int i = tid; i < nb; i += 256) {
-        const int p = cornerAt(i);
+    // Each wave scores its own corners; the block meets only afterwards, when the NMS needs the whole map.
+    for (int i = lane; i < nb_w; i += 64) {
+        const int p = mineB[i];
         const int sy = (p >> 7) & 63, sx = p & 127;
         const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
         const int sgn = (p & 0x2000) ? 1 : -1;
@@ -417,6 +430,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     }
     __syncthreads();
     VO_FAST_PHASE_END(3);
+    const int b0 = cntB[0], b1 = b0 + cntB[1], b2 = b1 + cntB[2], nb = b2 + cntB[3];
+    auto cornerAt = [&](int i) {
+        const int seg = (i >= b0) + (i >= b1) + (i >= b2);
+        return (int)listB[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? b0 : seg == 2 ? b1 : b2)];
+    };
 
     // phase D: NMS + border filter on the corners inside the tile
     const int b = max(border, 3);
