@@ -317,30 +317,43 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     int na = 0;  // survivors of this wave (wave-uniform)
     uint16_t* mineA = listA + wv * FT_LCAP;
     {
-        auto compass = [&](int sy, int sx, bool in) {
-            const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
+        // One compare decides a pixel: with mD = max(min(r0, r8), min(r4, r12)) and mB = min(max(r0, r8),
+        // max(r4, r12)), dark <=> mD < v - t and bright <=> mB > v + t, i.e. max(v - mD, mB - v) > t.  The
+        // image-border conditions go into the threshold (32767 where the pixel cannot be a corner: the
+        // column part once per lane, the row part wave-uniform), so the compare's mask is the ballot itself
+        // and no lane mask has to be rebuilt from scalar conditions.
+        // thr: the lane's threshold, 32767 where the pixel cannot be a corner (e never exceeds 510)
+        auto compass = [&](int sy, int sx, short thr) {
             const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
             // 16-bit arithmetic: two-operand 16-bit min / max issue in 2.3 cycles, 32-bit ones in 4.15
-            // (the compiler turns the eight compares into six min / max and two compares)
             short v = c[0], r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
             // the five reads happen for every (sy, sx), outside any branch on the border conditions
             pin_loaded(v), pin_loaded(r0), pin_loaded(r4), pin_loaded(r8), pin_loaded(r12);
-            const short lo = (short)(v - (short)threshold), hi = (short)(v + (short)threshold);
-            const bool d0 = r0 < lo, d4 = r4 < lo, d8 = r8 < lo, d12 = r12 < lo;
-            const bool b0 = r0 > hi, b4 = r4 > hi, b8 = r8 > hi, b12 = r12 > hi;
-            // two adjacent compass points of one polarity = one of {0, 8} and one of {4, 12}
-            const bool inside = in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3);
-            const bool surv = inside & (((d0 | d8) & (d4 | d12)) | ((b0 | b8) & (b4 | b12)));
-            const unsigned long long m = __ballot(surv);
+            const short mD = max(min(r0, r8), min(r4, r12)), mB = min(max(r0, r8), max(r4, r12));
+            const short e = max((short)(v - mD), (short)(mB - v));
+            const bool surv = e > thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
             if (m) {
                 if (surv) mineA[na + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
                 na += __popcll(m);
             }
         };
-        for (int sy = wv; sy < SM_H; sy += 4) compass(sy, lane, true);
+        auto border_thr = [&](int sy, int sx, bool in) {
+            const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
+            short thr = (in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3)) ? (short)threshold : (short)32767;
+            asm volatile("" : "+v"(thr));  // opaque: the compiler would turn it back into compare-and-mask
+            return thr;
+        };
+        {
+            // rows outside the image (wave-uniform) are skipped, the column condition is the lane's threshold
+            const short thr = border_thr(3 - (ty0 - 1), lane, true);
+            const int sy_lo = 3 - (ty0 - 1), sy_hi = min(h - 3 - (ty0 - 1), SM_H);  // 3 <= y < h - 3
+            for (int sy = wv + 4 * (max(sy_lo - wv + 3, 0) >> 2); sy < sy_hi; sy += 4) compass(sy, lane, thr);
+        }
         if (wv >= 2) {
             const int q = (wv - 2) * 64 + lane;  // 0 .. 2 * SM_H - 1
-            compass(min(q >> 1, SM_H - 1), FT_W + (q & 1), q < 2 * SM_H);
+            const int sy = min(q >> 1, SM_H - 1), sx = FT_W + (q & 1);
+            compass(sy, sx, border_thr(sy, sx, q < 2 * SM_H));
         }
     }
     wave_lds_sync();
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 // a 9-arc of one polarity excludes one of the other (16 ring points): bit 13 = dark arc
                 p |= (rd & 0xffffu) ? 0x2000 : 0;
             }
-            const unsigned long long m = __ballot(corner);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
             if (corner) mineB[nb_w + mbcnt(m)] = (uint16_t)p;
             nb_w += __popcll(m);
         }
