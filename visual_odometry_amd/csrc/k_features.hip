@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 // k_cand_write.
 // ---------------------------------------------------------------------------------------------
 #define FT_W 64
-#define FT_H 32
+#define FT_H VO_FT_H
 #define SM_W (FT_W + 2)
 #define SM_H (FT_H + 2)
 #define PX_W (FT_W + 8)
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 #define VO_FAST_PHASE_END(n)                                                                      \
     if (VO_FAST_STOP == (n)) {                                                                    \
         unsigned acc_ = cntA[tid & 3] + cntB[tid & 3];  /* keep the phases' results alive */      \
-        for (int i_ = tid; i_ < 4 * FT_LCAP; i_ += 256) acc_ += listA[i_] + listB[i_];           \
+        for (int i_ = tid; i_ < 4 * FT_LCAP; i_ += 256) acc_ += listA[i_];                        \
         acc_ += sm[tid % SM_H][tid % SM_W];                                                       \
         if (acc_ == 0x12345678u) rowmask[0][0] = 1;                                               \
         __syncthreads();                                                                          \
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 #else
 #define VO_FAST_PHASE_END(n)
 #endif
-#define FT_LCAP 704  // >= 9 rows x 64 + 68 pixels of phase A per wave, >= 11 x 64 candidates of phase B
+// entries of a wave's list: its rows of phase A (every fourth of the score region) x 64 + one more step
+#define FT_LCAP (((SM_H + 3) / 4) * 64 + 64)
 
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
@@ -240,9 +241,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
     __shared__ __attribute__((aligned(4))) uint8_t sm[SM_H][SM_W + 2];
     // survivor / corner lists: one private region per wave (no atomics, no cross-wave ordering
-    // needed: the lists only feed the score map); entries are sy << 7 | sx
+    // needed: the lists only feed the score map); entries are sy << 7 | sx.  The corner list of phase B
+    // is written over the survivor list it is compacted from: a step reads entries i0 .. i0 + 63 before
+    // it writes, and writes below i0 + 64.
     __shared__ uint16_t listA[4 * FT_LCAP];
-    __shared__ uint16_t listB[4 * FT_LCAP];
+    uint16_t* const listB = listA;
     __shared__ uint32_t rowmask[FT_H][2];
     __shared__ int cntB[4];
 #ifdef VO_FAST_STOP
@@ -260,12 +263,15 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const int w = L.w, h = L.h, pitch = L.pitch;
     const uint8_t* img = level_px(pyr, g, f, l);
 
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
+
     // phase 0
     {
         constexpr int N0 = PX_H * (PX_W / 4), STEPS = (N0 + 255) / 256;
-        uint32_t d[STEPS];  // all loads of the thread in flight together
+        uint32_t d[STEPS] = {};  // all loads of the thread in flight together
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
+            if (s >= N0 / 256 && 256 * s + 64 * wv >= N0) continue;  // a wave beyond the end of the last step
             const int i = min(tid + 256 * s, N0 - 1);
             const int r = i / (PX_W / 4), c4 = i - r * (PX_W / 4);
             const int gy = min(max(ty0 - 4 + r, -VO_PADY), h + VO_PADY - 1);
@@ -281,11 +287,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
     {
         constexpr int SM_DW = SM_H * (SM_W + 2) / 4;
-        static_assert(SM_DW > 512 && SM_DW <= 768, "three stores per thread clear the score map");
         uint32_t* sm32 = reinterpret_cast<uint32_t*>(&sm[0][0]);
-        sm32[tid] = 0;
-        sm32[tid + 256] = 0;
-        if (tid < SM_DW - 512) sm32[tid + 512] = 0;
+#pragma unroll
+        for (int s = 0; s < SM_DW / 256; s++) sm32[tid + 256 * s] = 0;
+        if (tid < SM_DW % 256) sm32[tid + 256 * (SM_DW / 256)] = 0;
     }
     if (tid < FT_H * 2) (&rowmask[0][0])[tid] = 0;
     __syncthreads();
@@ -300,8 +305,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     };
     VO_FAST_PHASE_END(0);
 
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
-
     // A wave's order of LDS operations is the order of its instructions, so between a phase's writes to the
     // wave's own list and the next phase's reads of it only the compiler has to be held back: no block barrier.
     auto wave_lds_sync = [] {
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     };
 
     // phase A: compass test.  Wave w takes the rows w, w + 4, ... of the score region with lane =
-    // column; columns 64 and 65 of all rows are one more step for waves 2 and 3 (they have a row less).
+    // column; columns 64 and 65 of all rows are one more step for the last waves.
     // Branch-free per row: the LDS reads are in range for every (sy, sx) of the score region, the
     // image-border conditions are folded into the survivor mask, so that mask is the ballot itself.
     int na = 0;  // survivors of this wave (wave-uniform)
@@ -338,20 +341,28 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 na += __popcll(m);
             }
         };
+        // a pixel outside the detector region (keypoint rectangle + the ring the NMS reads) needs no score
+        const int rx1 = L.rx0 + L.rw, ry1 = L.ry0 + L.rh;
         auto border_thr = [&](int sy, int sx, bool in) {
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-            short thr = (in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3)) ? (short)threshold : (short)32767;
+            short thr = (in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3) & (x >= L.rx0) & (x < rx1) &
+                         (y >= L.ry0) & (y < ry1))
+                            ? (short)threshold
+                            : (short)32767;
             asm volatile("" : "+v"(thr));  // opaque: the compiler would turn it back into compare-and-mask
             return thr;
         };
         {
-            // rows outside the image (wave-uniform) are skipped, the column condition is the lane's threshold
-            const short thr = border_thr(3 - (ty0 - 1), lane, true);
-            const int sy_lo = 3 - (ty0 - 1), sy_hi = min(h - 3 - (ty0 - 1), SM_H);  // 3 <= y < h - 3
+            // rows outside the image or the region (wave-uniform) are skipped, the column condition is the
+            // lane's threshold
+            const int y_lo = max(3, L.ry0), y_hi = min(h - 3, ry1);  // y_lo <= y < y_hi
+            const short thr = border_thr(y_lo - (ty0 - 1), lane, true);
+            const int sy_lo = y_lo - (ty0 - 1), sy_hi = min(y_hi - (ty0 - 1), SM_H);
             for (int sy = wv + 4 * (max(sy_lo - wv + 3, 0) >> 2); sy < sy_hi; sy += 4) compass(sy, lane, thr);
         }
-        if (wv >= 2) {
-            const int q = (wv - 2) * 64 + lane;  // 0 .. 2 * SM_H - 1
+        static_assert(2 * SM_H <= 3 * 64, "columns 64 and 65 fit one step of waves 3, 2, 1");
+        if ((3 - wv) * 64 < 2 * SM_H) {
+            const int q = (3 - wv) * 64 + lane;  // 0 .. 2 * SM_H - 1
             const int sy = min(q >> 1, SM_H - 1), sx = FT_W + (q & 1);
             compass(sy, sx, border_thr(sy, sx, q < 2 * SM_H));
         }
@@ -400,8 +411,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 rd &= xd >> 8;
                 rb &= xb >> 8;
                 corner = ((rd | rb) & 0xffffu) != 0;
-                // a 9-arc of one polarity excludes one of the other (16 ring points): bit 13 = dark arc
-                p |= (rd & 0xffffu) ? 0x2000 : 0;
+                // a 9-arc of one polarity excludes one of the other (16 ring points): bit 14 = dark arc
+                p |= (rd & 0xffffu) ? 0x4000 : 0;
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
             if (corner) mineB[nb_w + mbcnt(m)] = (uint16_t)p;
@@ -421,9 +432,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     // Each wave scores its own corners; the block meets only afterwards, when the NMS needs the whole map.
     for (int i = lane; i < nb_w; i += 64) {
         const int p = mineB[i];
-        const int sy = (p >> 7) & 63, sx = p & 127;
+        const int sy = (p >> 7) & 127, sx = p & 127;
         const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-        const int sgn = (p & 0x2000) ? 1 : -1;
+        const int sgn = (p & 0x4000) ? 1 : -1;
         const int sv = sgn * (int)c[0];
         int e[16];
 #define VO_E(k, dx, dy) e[k] = sv - sgn * (int)c[(dy) * PX_W + (dx)];
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     uint8_t* sc = level_px(score, g, f, l);
     for (int i = tid; i < nb; i += 256) {
         const int p = cornerAt(i);
-        const int sy = (p >> 7) & 63, sx = p & 127;
+        const int sy = (p >> 7) & 127, sx = p & 127;
         if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;
         const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
         if (!level_ok || x < b || x >= w - b || y < b || y >= h - b) continue;

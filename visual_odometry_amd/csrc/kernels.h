@@ -19,6 +19,9 @@ static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / 
 // pyramid, the blurred pyramid and the (sparsely written) FAST score map.
 #define VO_PADX 16
 #define VO_PADY 4
+#ifndef VO_FT_H
+#define VO_FT_H 64  // rows of a detector tile (k_fast_nms); tiles are 64 pixels wide
+#endif
 struct LevelGeom {
     int w, h;
     int pitch;
@@ -30,13 +33,13 @@ struct LevelGeom {
     // mask rows are counted inside it: segment (y, s) covers x = rx0 + 64 s .. + 63 of row ry0 + y.
     int rx0, ry0, rw, rh;
     int seg0, segs;   // first 64-pixel row segment of this level in the frame-wide mask table, segments per row
-    int tile0, tiles_x;  // first 64x32 detector tile of this level, tiles per tile row
+    int tile0, tiles_x;  // first 64 x VO_FT_H detector tile of this level, tiles per tile row
 };
 struct PyrGeom {
     int nlevels;
     int rows_total;      // sum of level heights
     unsigned pyr_bytes;  // packed bytes per frame
-    int tiles_total;     // 64x32 tiles over all levels
+    int tiles_total;     // 64 x VO_FT_H tiles over all levels
     int segs_total;      // 64-pixel row segments over all levels
     LevelGeom lv[VO_ORB_MAX_LEVELS];
 };

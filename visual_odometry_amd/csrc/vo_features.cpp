@@ -139,7 +139,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
             seg += L.segs * L.rh;
             L.tiles_x = L.segs;
             L.tile0 = tile;
-            tile += L.tiles_x * cdiv(L.rh, 32);
+            tile += L.tiles_x * cdiv(L.rh, VO_FT_H);
         }
         g.tiles_total = tile;
         g.segs_total = seg;
