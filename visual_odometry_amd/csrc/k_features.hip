@@ -31,6 +31,28 @@ __device__ __forceinline__ int mbcnt(unsigned long long m) {
 // Pins a loaded value at this point of the program: without it the compiler sinks a load whose only
 // use is conditional into the branch, which turns a batch of independent loads into a chain of
 // load -> wait -> load.
+// Three-input forms written out: left to itself the compiler re-associates the arc networks of k_fast_nms into
+// more two-input instructions (63 and 44 where 40 do).
+__device__ __forceinline__ uint32_t and3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t or3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int min3i(int a, int b, int c) {
+    int d;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int max3i(int a, int b, int c) {
+    int d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 template <class T>
 __device__ __forceinline__ void pin_loaded(T& v) {
     asm volatile("" : "+v"(v));
@@ -247,9 +269,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     __shared__ uint16_t listA[4 * FT_LCAP];
     uint16_t* const listB = listA;
     __shared__ uint32_t rowmask[FT_H][2];
-    __shared__ int cntB[4];
 #ifdef VO_FAST_STOP
-    __shared__ int cntA[4];  // only the phase-counting variants read the survivor counts across waves
+    __shared__ int cntA[4], cntB[4];  // only the phase-counting variants read the survivor counts across waves
 #endif
     const uint8_t* px = reinterpret_cast<const uint8_t*>(px4);
     const int f = blockIdx.y, tid = threadIdx.x;
@@ -265,24 +286,38 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave index in an SGPR
 
-    // phase 0
+    // phase 0: thread (r0, c) of 14 x 18 takes dword c of the rows r0, r0 + 14, ... of the pixel tile.  A tile
+    // whose rectangle lies inside the level's padded storage (all but some tiles of the last tile row /
+    // column) needs one 32-bit offset per thread and a wave-uniform base per step; the others clamp.
     {
-        constexpr int N0 = PX_H * (PX_W / 4), STEPS = (N0 + 255) / 256;
+        constexpr int RW = PX_W / 4, RPS = 256 / RW, STEPS = (PX_H + RPS - 1) / RPS;
+        const int r0 = (tid * ((65536 + RW - 1) / RW)) >> 16, c4 = tid - r0 * RW;
+        static_assert(RW == 18 && RPS == 14, "r0 = tid / 18 by multiplication is exact for tid < 256");
+        const bool act = tid < RW * RPS;
         uint32_t d[STEPS] = {};  // all loads of the thread in flight together
+        const bool interior = tx0 - 4 + PX_W <= pitch - VO_PADX && ty0 - 4 + PX_H <= h + VO_PADY &&
+                              tx0 - 4 >= -VO_PADX && ty0 - 4 >= -VO_PADY;
+        if (interior) {
+            const uint8_t* base = img + (ptrdiff_t)(ty0 - 4) * pitch + (tx0 - 4);
+            const uint32_t voff = (uint32_t)(r0 * pitch + 4 * c4);
 #pragma unroll
-        for (int s = 0; s < STEPS; s++) {
-            if (s >= N0 / 256 && 256 * s + 64 * wv >= N0) continue;  // a wave beyond the end of the last step
-            const int i = min(tid + 256 * s, N0 - 1);
-            const int r = i / (PX_W / 4), c4 = i - r * (PX_W / 4);
-            const int gy = min(max(ty0 - 4 + r, -VO_PADY), h + VO_PADY - 1);
+            for (int s = 0; s < STEPS; s++)
+                if (act && r0 + RPS * s < PX_H)
+                    d[s] = *reinterpret_cast<const uint32_t*>(base + (ptrdiff_t)(RPS * s) * pitch + voff);
+        } else {
             const int gx = min(max(tx0 - 4 + 4 * c4, -VO_PADX), pitch - VO_PADX - 4);
-            d[s] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
+#pragma unroll
+            for (int s = 0; s < STEPS; s++) {
+                const int gy = min(max(ty0 - 4 + r0 + RPS * s, -VO_PADY), h + VO_PADY - 1);
+                if (act && r0 + RPS * s < PX_H)
+                    d[s] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)gy * pitch + gx);
+            }
         }
 #pragma unroll
         for (int s = 0; s < STEPS; s++) pin_loaded(d[s]);
 #pragma unroll
         for (int s = 0; s < STEPS; s++)
-            if (tid + 256 * s < N0) px4[tid + 256 * s] = d[s];
+            if (act && r0 + RPS * s < PX_H) px4[tid + RW * RPS * s] = d[s];
     }
     static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
     {
@@ -386,42 +421,39 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                 p = mineA[i];
                 const int sy = p >> 7, sx = p & 127;
                 const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-                const int v = c[0], lo = v - threshold, hi = v + threshold;
-                // bit k of dark / bright: ring point k is darker than lo / brighter than hi.  The sign bit
-                // of r - lo (hi - r) is shifted in with one v_alignbit per point, point 15 first.
-                uint32_t dark = 0, bright = 0;
-#define VO_RING(dx, dy)                                                                  \
-    {                                                                                    \
-        const int r = c[(dy) * PX_W + (dx)];                                             \
-        dark = __builtin_amdgcn_alignbit(dark, (uint32_t)(r - lo), 31);                  \
-        bright = __builtin_amdgcn_alignbit(bright, (uint32_t)(hi - r), 31);              \
-    }
-                VO_RING(-1, 3) VO_RING(-2, 2) VO_RING(-3, 1) VO_RING(-3, 0)
-                VO_RING(-3, -1) VO_RING(-2, -2) VO_RING(-1, -3) VO_RING(0, -3)
-                VO_RING(1, -3) VO_RING(2, -2) VO_RING(3, -1) VO_RING(3, 0)
-                VO_RING(3, 1) VO_RING(2, 2) VO_RING(1, 3) VO_RING(0, 3)
+                const uint32_t tt = (uint32_t)threshold * 65537u;
+                // One multiply-add per ring point gives both tests: P = (r - v + t) + ((v + t - r) << 16) has bit 15
+                // set iff r < v - t (dark) and bit 31 set iff r > v + t (bright) -- the fields stay within 16 bits
+                // and the borrow of a negative low field never flips the high one, which is > 2t then.  A 9-arc
+                // of one polarity is a non-zero bit 15 / 31 in the AND of nine consecutive words: two levels of
+                // three-input ANDs for the 16 arcs, three-input ORs over them.
+                const uint32_t C = (uint32_t)c[0] * 65535u + tt;
+                uint32_t P[16];
+#define VO_RING(k, dx, dy) P[k] = C - 65535u * (uint32_t)c[(dy) * PX_W + (dx)];
+                VO_RING(0, -1, 3) VO_RING(1, -2, 2) VO_RING(2, -3, 1) VO_RING(3, -3, 0)
+                VO_RING(4, -3, -1) VO_RING(5, -2, -2) VO_RING(6, -1, -3) VO_RING(7, 0, -3)
+                VO_RING(8, 1, -3) VO_RING(9, 2, -2) VO_RING(10, 3, -1) VO_RING(11, 3, 0)
+                VO_RING(12, 3, 1) VO_RING(13, 2, 2) VO_RING(14, 1, 3) VO_RING(15, 0, 3)
 #undef VO_RING
-                // >= 9 contiguous set bits on the 16-ring
-                const uint32_t xd = dark | (dark << 16), xb = bright | (bright << 16);
-                uint32_t rd = xd & (xd >> 1), rb = xb & (xb >> 1);
-                rd &= rd >> 2;
-                rb &= rb >> 2;
-                rd &= rd >> 4;
-                rb &= rb >> 4;
-                rd &= xd >> 8;
-                rb &= xb >> 8;
-                corner = ((rd | rb) & 0xffffu) != 0;
+                uint32_t t3[16], a9[16], any = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) t3[k] = and3(P[k], P[(k + 1) & 15], P[(k + 2) & 15]);
+#pragma unroll
+                for (int k = 0; k < 16; k++) a9[k] = and3(t3[k], t3[(k + 3) & 15], t3[(k + 6) & 15]);
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) any = or3(any, a9[k], a9[k + 1]);
+                corner = (any & 0x80008000u) != 0;
                 // a 9-arc of one polarity excludes one of the other (16 ring points): bit 14 = dark arc
-                p |= (rd & 0xffffu) ? 0x4000 : 0;
+                p |= (any >> 1) & 0x4000;
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);
             if (corner) mineB[nb_w + mbcnt(m)] = (uint16_t)p;
             nb_w += __popcll(m);
         }
-        if (lane == 0) cntB[wv] = nb_w;
     }
     wave_lds_sync();
 #ifdef VO_FAST_STOP
+    if (lane == 0) cntB[wv] = nb_w;
     __syncthreads();
 #endif
     VO_FAST_PHASE_END(2);
@@ -434,54 +466,52 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         const int p = mineB[i];
         const int sy = (p >> 7) & 127, sx = p & 127;
         const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-        const int sgn = (p & 0x4000) ? 1 : -1;
-        const int sv = sgn * (int)c[0];
+        // e = v - ring for a dark arc, ring - v for a bright one: one multiply-add per point
+        const int nsgn = (p & 0x4000) ? -1 : 1;
+        const int sv = -nsgn * (int)c[0];
         int e[16];
-#define VO_E(k, dx, dy) e[k] = sv - sgn * (int)c[(dy) * PX_W + (dx)];
+#define VO_E(k, dx, dy) e[k] = nsgn * (int)c[(dy) * PX_W + (dx)] + sv;
         VO_E(0, 0, 3) VO_E(1, 1, 3) VO_E(2, 2, 2) VO_E(3, 3, 1) VO_E(4, 3, 0) VO_E(5, 3, -1) VO_E(6, 2, -2)
         VO_E(7, 1, -3) VO_E(8, 0, -3) VO_E(9, -1, -3) VO_E(10, -2, -2) VO_E(11, -3, -1) VO_E(12, -3, 0)
         VO_E(13, -3, 1) VO_E(14, -2, 2) VO_E(15, -1, 3)
 #undef VO_E
+        // minimum over each of the 16 arcs of nine points: two levels of three-input minima
         int best = threshold;
-        int m2[16], m4[16];
+        int m3[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m2[k] = min(e[k], e[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m3[k] = min3i(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
+        int m9[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+        for (int k = 0; k < 16; k++) m9[k] = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) best = max(best, min(min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+        for (int k = 0; k < 16; k += 2) best = max3i(best, m9[k], m9[k + 1]);
         sm[sy][sx] = (uint8_t)best;  // (best - 1) + 1
     }
     __syncthreads();
     VO_FAST_PHASE_END(3);
-    const int b0 = cntB[0], b1 = b0 + cntB[1], b2 = b1 + cntB[2], nb = b2 + cntB[3];
-    auto cornerAt = [&](int i) {
-        const int seg = (i >= b0) + (i >= b1) + (i >= b2);
-        return (int)listB[seg * FT_LCAP + i - (seg == 0 ? 0 : seg == 1 ? b0 : seg == 2 ? b1 : b2)];
-    };
 
-    // phase D: NMS + border filter on the corners inside the tile
+    // phase D: NMS + border filter on the corners inside the tile, every wave on its own corners
     const int b = max(border, 3);
     const bool level_ok = border == 0 || (w > 2 * border && h > 2 * border);
     uint8_t* sc = level_px(score, g, f, l);
-    for (int i = tid; i < nb; i += 256) {
-        const int p = cornerAt(i);
+    for (int i = lane; i < nb_w; i += 64) {
+        const int p = mineB[i];
         const int sy = (p >> 7) & 127, sx = p & 127;
-        if (sx < 1 || sx > FT_W || sy < 1 || sy > FT_H) continue;
         const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-        if (!level_ok || x < b || x >= w - b || y < b || y >= h - b) continue;
-        const int s1 = sm[sy][sx];
+        const bool in = (sx >= 1) & (sx <= FT_W) & (sy >= 1) & (sy <= FT_H) & level_ok & (x >= b) & (x < w - b) &
+                        (y >= b) & (y < h - b);
+        if (!in) continue;
+        const uint8_t* q = &sm[sy][sx];
+        const int s1 = q[0];
         bool kp = true;
         if (nms) {
-            // the map holds score + 1 (0 = not a corner); cv compares the score with the
-            // neighbours' scores, a neighbour that is not a corner counting as 0
-            const int s = s1 - 1;
-            auto nb8 = [&](int dy, int dx) {
-                const int q = sm[sy + dy][sx + dx];
-                return q ? q - 1 : 0;
-            };
-            kp = s > nb8(0, -1) && s > nb8(0, 1) && s > nb8(-1, -1) && s > nb8(-1, 0) && s > nb8(-1, 1) &&
-                 s > nb8(1, -1) && s > nb8(1, 0) && s > nb8(1, 1);
+            // The map holds score + 1 (0 = not a corner); cv keeps a corner whose score exceeds the scores of
+            // its eight neighbours, a neighbour that is not a corner counting as 0: s1 - 1 > (q ? q - 1 : 0)
+            // for all eight, i.e. s1 > max(1, the eight map values).
+            constexpr int SP = SM_W + 2;
+            const int a0 = q[-SP - 1], a1 = q[-SP], a2 = q[-SP + 1], a3 = q[-1], a4 = q[1], a5 = q[SP - 1], a6 = q[SP],
+                      a7 = q[SP + 1];
+            kp = s1 > max(max(max(max(a0, a1), a2), max(max(a3, a4), a5)), max(max(a6, a7), 1));
         }
         if (kp) {
             atomicOr(&rowmask[sy - 1][(sx - 1) >> 5], 1u << ((sx - 1) & 31));
