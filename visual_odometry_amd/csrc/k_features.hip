@@ -1276,6 +1276,34 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
 // (largest pattern norm 18.4), so the 37 x 37 window is first copied to LDS with aligned dword loads,
 // three rows of ten dwords per step, and the 512 scattered byte reads per keypoint go to LDS.
 // ---------------------------------------------------------------------------------------------
+// (float)cos(a), (float)sin(a) of a double a in [0, 2 pi]: quadrant by two-part Cody-Waite reduction (k <= 4, so
+// k * PIO2_HI is exact), fdlibm's kernel polynomials on |r| <= pi / 4, errors below one double ulp -- the
+// float results differ from those of a correctly rounded double cos / sin only when that ulp straddles a
+// float rounding boundary (2^-29 of all arguments).  ~45 double instructions instead of the library
+// routine's ~200, which every block's first wave ran alone while the other three waited at the barrier.
+__device__ __forceinline__ void sincos_2pi(double a, float& cf, float& sf) {
+    const double kd = __builtin_rint(a * 6.36619772367581382433e-01);
+    const int q = (int)kd;
+    double r = __builtin_fma(-kd, 1.57079632673412561417e+00, a);
+    r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = 1.0 - __builtin_fma(z, 0.5, -(z * (z * pc)));
+    const double c4 = (q & 1) ? sn : cs, s4 = (q & 1) ? cs : sn;
+    cf = (float)(((q + 1) & 2) ? -c4 : c4);
+    sf = (float)((q & 2) ? -s4 : s4);
+}
+
 __constant__ __attribute__((aligned(16))) int8_t c_orb_pattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -1338,8 +1366,7 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     }
     if (tid < RB_KP) {  // overlaps the window loads
         angle *= (float)(3.14159265358979323846 / 180.f);
-        s_ca[tid] = (float)cos((double)angle);
-        s_sa[tid] = (float)sin((double)angle);
+        sincos_2pi((double)angle, s_ca[tid], s_sa[tid]);
     }
 #pragma unroll
     for (int i = 0; i < (RB_ROWS + 2) / 3; i++) {
@@ -1349,7 +1376,13 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     __syncthreads();
     if (!live) return;
     const float ca = s_ca[slot], sa = s_sa[slot];
-    const uint8_t* center = reinterpret_cast<const uint8_t*>(win[slot]) + RB_R * (4 * RB_DW) + RB_R + o;
+    // cvRound by the magic constant: y + 1.5 * 2^23 holds rint(y) in its low mantissa bits, so one 24-bit
+    // multiply-add of the two bit patterns is row * 40 + column plus a constant that goes into the base
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    constexpr float MAGIC = 12582912.f;
+    constexpr uint32_t MAGIC_K = 0x4B400000u + (uint32_t)(4 * RB_DW) * 0x400000u;
+    const uint32_t center = (uint32_t)(uintptr_t)(lds_u8*)(reinterpret_cast<const uint8_t*>(win[slot]) +
+                                                           RB_R * (4 * RB_DW) + RB_R + o) - MAGIC_K;
     const float2* p = reinterpret_cast<const float2*>(patf) + b * 16;
     int val = 0;
 #pragma unroll
@@ -1360,7 +1393,8 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
             const float2 pt = p[2 * t + e];
             const float x = pt.x * ca - pt.y * sa;
             const float y = pt.x * sa + pt.y * ca;
-            v[e] = center[__float2int_rn(y) * (4 * RB_DW) + __float2int_rn(x)];
+            const int at = __mul24(__builtin_bit_cast(int, y + MAGIC), 4 * RB_DW) + __builtin_bit_cast(int, x + MAGIC);
+            v[e] = *(lds_u8*)(uintptr_t)(center + (uint32_t)at);
         }
         val |= (v[0] < v[1]) << t;
     }
