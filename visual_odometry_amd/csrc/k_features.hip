@@ -205,15 +205,16 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
         const uint32_t CY = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
         const uint8_t* r0 = t8 + __umul24(oy - sy0, ldw * 4);
         const uint8_t* r1 = r0 + ldw * 4;
-        uint32_t out = 0;
+        uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const vo_u16x2 A = {r0[ox[j]], r1[ox[j]]}, B = {r0[ox[j] + 1], r1[ox[j] + 1]};
             const vo_u16x2 hp = A * CX0[j] + B * CX1[j];
-            const uint32_t v = udot2(__builtin_bit_cast(uint32_t, hp), CY, 32768u) >> 16;
-            out |= min(v, 255u) << (8 * j);
+            v[j] = udot2(__builtin_bit_cast(uint32_t, hp), CY, 32768u);
         }
-        *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = out;
+        // the weights sum to 2^16, so v < 2^24 and the pixel is byte 2 of v: no clamp, three byte permutes
+        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+        *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
     }
 }
 
