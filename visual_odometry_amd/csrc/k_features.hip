@@ -128,19 +128,22 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
 // reflected: xtab[i] belongs to x = i - 4, ytab[i] to y = i - 3, so the reflect-101 frame of the
 // new level is produced by the same code as its interior.  A block makes 256 x PR_ROWS pixels: the
 // source rectangle they read (known from the tables, which are monotone in the reflected
-// coordinate) is staged in LDS with aligned dword loads, then every thread makes four pixels of two
-// rows from LDS bytes and stores aligned dwords.
+// coordinate) is staged in LDS as one dword per source pixel holding the pixel and the one below it
+// in its 16-bit halves -- the operand the packed 16-bit arithmetic of the interpolation takes -- so an
+// output pixel costs two LDS dword reads (one ds_read2) and five vector instructions.
 // ---------------------------------------------------------------------------------------------
 struct ResizeArgs {  // geometry of the two levels, from the host copy: nothing to fetch before the tables
     int dw, dh, dpitch, sw, sh, spitch;
     unsigned soff, doff, pyr_bytes;  // level offsets include the padding rows and columns
-    int ldw;
+    int ldw;                         // source dwords per tile row (the level's maximum)
+    unsigned magic;                  // ceil(65536 / ldw): tid / ldw for tid < 256 by one multiplication
+    int ngroups, grows;              // tile fill: 256 / ldw row groups of `grows` pair rows each
 };
 
 __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, ResizeArgs a,
                                                     const uint32_t* __restrict__ xtab,
                                                     const uint32_t* __restrict__ ytab) {
-    extern __shared__ uint32_t rs_tile[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t rs_tile[];
     const int f = blockIdx.z, tid = threadIdx.x;
     const int dw = a.dw, dh = a.dh, dpitch = a.dpitch, sw = a.sw, sh = a.sh, spitch = a.spitch, ldw = a.ldw;
     const int xa = -4 + 256 * (int)blockIdx.x, ya = -3 + PR_ROWS * (int)blockIdx.y;
@@ -156,24 +159,34 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
     vo_reflect_range(ya, min(ya + PR_ROWS - 1, dh + 2), dh, lo, hi);
     const int sy0 = (int)(ytab[lo + 3] >> 16), sy1 = min((int)(ytab[hi + 3] >> 16) + 1, sh - 1);
     const int ndw = (sx1 - sx0) / 4 + 1, nrows = sy1 - sy0 + 1;  // <= ldw, <= the rows the launch sized LDS for
-    const uint8_t* s = pyr + (size_t)f * a.pyr_bytes + a.soff;
-    // tile fill without divisions: half a block per source row (columns c, c + 128, ...), six rows
-    // of loads in flight per thread
-    const int c0 = tid & 127, rh = tid >> 7;
-    for (int cb = 0; cb < ndw; cb += 128) {
-        const int c = cb + c0;
-        const uint8_t* col = s + (ptrdiff_t)sy0 * spitch + sx0 + 4 * min(c, ndw - 1);
-        for (int r0 = 0; r0 < nrows; r0 += 12) {
-            uint32_t d[6];
+    const int LP = 4 * ldw + 4;  // dwords per pair row: one per source pixel + the right neighbour of the last
+    const uint8_t* s = pyr + (size_t)f * a.pyr_bytes + a.soff + (ptrdiff_t)sy0 * spitch + sx0;
+    // Tile fill: thread (group, c) takes source dword c of the rows group * grows ... + grows (one more than it
+    // pairs up), all loads in flight, 32-bit offsets from a block-uniform base; pair row r of the tile is
+    // (row r, row r + 1), the last one (row nrows - 1 twice) only ever read with weight 0 on its lower half.
+    {
+        const int grp = (int)((tid * a.magic) >> 16), c = tid - grp * ldw;
+        const int cc = min(c, ndw - 1);  // idle threads (c >= ndw, or a group beyond the last) load in range
+        const int rend = (c < ndw && grp < a.ngroups) ? min((grp + 1) * a.grows, nrows) : 0;  // pair rows < rend are mine
+        for (int b0 = 0; b0 < a.grows; b0 += 8) {
+            const int r0 = grp * a.grows + b0;
+            uint32_t d[9];
 #pragma unroll
-            for (int u = 0; u < 6; u++)
-                d[u] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)min(r0 + rh + 2 * u, nrows - 1) * spitch);
+            for (int u = 0; u < 9; u++)
+                d[u] = *reinterpret_cast<const uint32_t*>(s + (uint32_t)(__mul24(min(r0 + u, nrows - 1), spitch) + 4 * cc));
 #pragma unroll
-            for (int u = 0; u < 6; u++) pin_loaded(d[u]);
+            for (int u = 0; u < 9; u++) pin_loaded(d[u]);
+            uint32_t* at = rs_tile + __mul24(r0, LP) + 4 * c;
 #pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const int r = r0 + rh + 2 * u;
-                if (c < ndw && r < nrows) rs_tile[r * ldw + c] = d[u];
+            for (int u = 0; u < 8; u++) {
+                if (r0 + u < rend) {
+                    uint4 e;
+                    e.x = __builtin_amdgcn_perm(d[u + 1], d[u], 0x0c040c00u);
+                    e.y = __builtin_amdgcn_perm(d[u + 1], d[u], 0x0c050c01u);
+                    e.z = __builtin_amdgcn_perm(d[u + 1], d[u], 0x0c060c02u);
+                    e.w = __builtin_amdgcn_perm(d[u + 1], d[u], 0x0c070c03u);
+                    *reinterpret_cast<uint4*>(at + u * LP) = e;
+                }
             }
         }
     }
@@ -182,8 +195,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
     // Packed 16-bit arithmetic: the (upper row, lower row) samples of a column share a dword, so one
     // v_pk_mul_lo_u16 + v_pk_mad_u16 interpolates both rows horizontally (h <= 256 * 255 fits 16 bits) and
     // one v_dot2_u32_u16 with (cy0, cy1) is the vertical pass; the same integers as the scalar form.  The
-    // right / lower neighbour is read unclamped: where cv clamps it (last column / row) its weight is 0,
-    // and the launch sizes the tile one row and 16 bytes larger so the read stays inside LDS.
+    // right / lower neighbour is read unclamped: where cv clamps it (last column / row) its weight is 0.
     const uint32_t tx[4] = {tx4.x, tx4.y, tx4.z, tx4.w};
     vo_u16x2 CX0[4], CX1[4];
     int ox[4];
@@ -194,7 +206,6 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
         CX0[j] = vo_u16x2{c0, c0};
         CX1[j] = vo_u16x2{c1, c1};
     }
-    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(rs_tile);
     uint8_t* dst = pyr + (size_t)f * a.pyr_bytes + a.doff;
 #pragma unroll
     for (int i = 0; i < PR_ROWS / 4; i++) {
@@ -203,18 +214,17 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
         const uint32_t ty = tyk[i];
         const int oy = ty >> 16, cy1 = ty & 0xffff, cy0 = 256 - cy1;
         const uint32_t CY = (uint32_t)cy0 | ((uint32_t)cy1 << 16);
-        const uint8_t* r0 = t8 + __umul24(oy - sy0, ldw * 4);
-        const uint8_t* r1 = r0 + ldw * 4;
+        const uint32_t* row = rs_tile + __umul24(oy - sy0, LP);
         uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const vo_u16x2 A = {r0[ox[j]], r1[ox[j]]}, B = {r0[ox[j] + 1], r1[ox[j] + 1]};
+            const vo_u16x2 A = __builtin_bit_cast(vo_u16x2, row[ox[j]]), B = __builtin_bit_cast(vo_u16x2, row[ox[j] + 1]);
             const vo_u16x2 hp = A * CX0[j] + B * CX1[j];
             v[j] = udot2(__builtin_bit_cast(uint32_t, hp), CY, 32768u);
         }
         // the weights sum to 2^16, so v < 2^24 and the pixel is byte 2 of v: no clamp, three byte permutes
-        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
-        *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        const uint32_t lo2 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), hi2 = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+        *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)y * dpitch + x4) = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
     }
 }
 
@@ -1427,8 +1437,15 @@ void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
     a.doff = D.offset + (unsigned)(VO_PADY * D.pitch + VO_PADX);
     a.pyr_bytes = hg.pyr_bytes;
     a.ldw = ldw;
+    a.magic = (65536u + (unsigned)ldw - 1) / (unsigned)ldw;
+    a.ngroups = std::max(256 / ldw, 1);
+    a.grows = cdiv(lrows, a.ngroups);
     dim3 grid(cdiv(D.w + 7, 256), cdiv(D.h + 6, PR_ROWS), nframes);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), (size_t)ldw * (lrows + 1) * 4 + 16, st, pyr, a, xtab, ytab);
+    const size_t lds = vo_resize_lds_bytes(ldw, lrows);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyr_resize),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), lds, st, pyr, a, xtab, ytab);
 }
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,

@@ -62,6 +62,9 @@ static inline __host__ __device__ void vo_reflect_range(int a, int b, int n, int
     hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
 }
 #define PR_ROWS 16  // destination rows per block of the pyramid resize
+// LDS tile of the resize kernel: `rows` pair rows of one dword per source pixel (4 * ldw of them) + 4
+static inline size_t vo_resize_lds_bytes(int ldw, int rows) { return (size_t)rows * (4 * (size_t)ldw + 4) * 4; }
+#define VO_RESIZE_LDS_MAX (160 * 1024)
 
 struct Taps7 {
     int t[7];

@@ -182,7 +182,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
                 const int sy0 = (int)(yt[lo + 3] >> 16), sy1 = std::min((int)(yt[hi + 3] >> 16) + 1, sh - 1);
                 rows = std::max(rows, sy1 - sy0 + 1);
             }
-            if ((size_t)ldw * (rows + 1) * 4 + 16 > 64 * 1024)
+            if (ldw > 256 || vo_resize_lds_bytes(ldw, rows) > VO_RESIZE_LDS_MAX)
                 return c->fail(VO_ERR_INVALID, "scale factor %g is too large for the resize tile", (double)sf);
             c->coef_ldw[l] = ldw;
             c->coef_rows[l] = rows;
