@@ -75,35 +75,45 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // run that path (the padding bytes beyond the 3-pixel frame get reflected values too; nothing reads
 // them as pixels).
 // ---------------------------------------------------------------------------------------------
-#define L0_ROWS 4  // rows per thread: four independent 16-byte loads in flight
+#define L0_ROWS 4    // rows per thread of the edge blocks
+#define L0_CHUNKS 4  // chunks per thread of the interior blocks: four independent 16-byte loads in flight
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
                                                     int w, int h, int pitch, unsigned pyr_bytes, unsigned loff,
-                                                    int nint, uint8_t* __restrict__ pyr) {
+                                                    int nedge_blocks, unsigned nch_magic, uint8_t* __restrict__ pyr) {
     const int f = blockIdx.z;
-    const int end_int = (w - 15 > 0 ? (w - 16) / 16 + 1 : 0) * 16;  // interior chunks: x = 0, 16, ... < end_int
-    const int y0 = -3 + ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * L0_ROWS;
-    if (y0 >= h + 3) return;
+    const int nch = w - 15 > 0 ? (w - 16) / 16 + 1 : 0;  // interior chunks of a row: x = 0, 16, ... < end_int
+    const int end_int = nch * 16;
     const uint8_t* fimg = img + (size_t)f * frame_stride;
     uint8_t* dst = pyr + (size_t)f * pyr_bytes + loff;
-    if ((int)blockIdx.x < nint) {
-        const int x16 = 16 * (int)(blockIdx.x * 64 + (threadIdx.x & 63));
-        if (x16 >= end_int) return;
-        uint4 v[L0_ROWS];
+    if ((int)blockIdx.x >= nedge_blocks) {  // the (slow, few) edge blocks go first and run beside the interior
+        const int bi = (int)blockIdx.x - nedge_blocks;
+        // interior: the (row, chunk) pairs of the frame in one sequence, chunk fastest, so that every lane has
+        // a chunk whatever the width; row = index / nch by a 32-bit reciprocal (exact for index < 2^16 * nch)
+        const int total = nch * (h + 6);
+        uint4 v[L0_CHUNKS];
+        int at[L0_CHUNKS];
 #pragma unroll
-        for (int i = 0; i < L0_ROWS; i++)
-            __builtin_memcpy(&v[i], fimg + (size_t)reflect101(min(y0 + i, h + 2), h) * stride + x16, 16);
+        for (int i = 0; i < L0_CHUNKS; i++) {
+            const int idx = min(bi * (256 * L0_CHUNKS) + 256 * i + (int)threadIdx.x, total - 1);
+            const int row = nch == 1 ? idx : (int)__umulhi((unsigned)idx, nch_magic), ch = idx - row * nch;
+            const int y = row - 3;
+            at[i] = y * pitch + 16 * ch;
+            __builtin_memcpy(&v[i], fimg + (size_t)reflect101(y, h) * stride + 16 * ch, 16);
+        }
 #pragma unroll
-        for (int i = 0; i < L0_ROWS; i++) {
+        for (int i = 0; i < L0_CHUNKS; i++) {
             pin_loaded(v[i].x);
             pin_loaded(v[i].y);
             pin_loaded(v[i].z);
             pin_loaded(v[i].w);
         }
 #pragma unroll
-        for (int i = 0; i < L0_ROWS; i++)
-            if (y0 + i < h + 3) *reinterpret_cast<uint4*>(dst + (ptrdiff_t)(y0 + i) * pitch + x16) = v[i];
+        for (int i = 0; i < L0_CHUNKS; i++)  // an index clamped to the last pair stores that pair again: same bytes
+            *reinterpret_cast<uint4*>(dst + (ptrdiff_t)at[i]) = v[i];
     } else {
         // edge chunks: x = -16, then end_int, end_int + 16, ... < w + 3
+        const int y0 = -3 + ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * L0_ROWS;
+        if (y0 >= h + 3) return;
         const int nedge = 1 + (w + 3 - end_int + 15) / 16;
         const int e = threadIdx.x & 63;
         if (e >= nedge) return;
@@ -1419,11 +1429,13 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
                        const PyrGeom& hg, uint8_t* pyr, int nframes) {
     (void)d_geom;
     const LevelGeom& L = hg.lv[0];
-    const int interior = L.w - 15 > 0 ? (L.w - 16) / 16 + 1 : 0;  // whole 16-byte chunks inside [0, w)
-    const int nint = cdiv(interior, 64);
-    dim3 grid(nint + 1, cdiv(L.h + 6, 4 * L0_ROWS), nframes);
+    const int nch = L.w - 15 > 0 ? (L.w - 16) / 16 + 1 : 0;  // whole 16-byte chunks inside [0, w)
+    const int nint = cdiv(nch * (L.h + 6), 256 * L0_CHUNKS);   // blocks of the interior
+    const unsigned magic = nch > 1 ? (unsigned)((0x100000000ull + (unsigned)nch - 1) / (unsigned)nch) : 0xffffffffu;
+    const int nedge_blocks = cdiv(L.h + 6, 4 * L0_ROWS);
+    dim3 grid(nedge_blocks + nint, 1, nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, L.w, L.h, L.pitch,
-                       hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), nint, pyr);
+                       hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), nedge_blocks, magic, pyr);
 }
 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
