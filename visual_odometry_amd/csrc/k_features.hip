@@ -239,15 +239,19 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 }
 
 // ---------------------------------------------------------------------------------------------
-// FAST-9/16 + cornerScore<16> + 3x3 strict-greater NMS + border filter, fused per 64 x 32 tile.
+// FAST-9/16 + cornerScore<16> + 3x3 strict-greater NMS + border filter, fused per 64 x VO_FT_H (64) tile.
 //   phase 0  tile pixels (+4 halo) -> LDS with aligned dword loads
 //   phase A  compass test (ring points 0,4,8,12: a 9-arc holds two adjacent ones) on every pixel
-//            of the 66 x 34 score region; survivors (about one pixel in eight) are compacted
-//   phase B  full 16-point arc test on the survivors, dense lanes; corners are compacted again
-//   phase C  cornerScore of the corners -> LDS score map (score + 1, 0 = not a corner)
+//            of the 66 x 66 score region; survivors (about one pixel in eight) are compacted
+//   phase B  full 16-point arc test on the survivors, dense lanes: one multiply-add per ring point carries
+//            both polarities, three-input AND / OR networks find the arc; corners are compacted in place
+//   phase C  cornerScore of the corners (min3 / max3 network on the arc's polarity) -> LDS score map
+//            (score + 1, 0 = not a corner)
 //   phase D  NMS + border filter of the corners inside the tile -> per-row 64-bit masks in LDS,
 //            score byte of each keypoint -> sparse global score map
 //   phase E  one 64-bit mask per tile row -> global mask table
+// The tile is 64 rows high so that a wave's lists (a quarter of the rows) fill the lanes of phases B and C:
+// with 32 rows a wave had ~73 survivors and ~28 corners, i.e. two steps of B at 57 % and one of C at 44 %.
 // Phases A, B and C run per wave on the wave's own rows and lists (a wave's LDS operations complete in
 // order, so no block barrier separates them); the block meets after phase 0, before the NMS and before E.
 // Row-major keypoint order (what cv's FAST emits) is rebuilt from the masks by k_row_scan /
