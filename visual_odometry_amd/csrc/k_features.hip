@@ -1377,17 +1377,33 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     const int xw = (cx - RB_R) & ~3, o = cx - RB_R - xw;
     const bool stage = live && b < 3 * RB_DW;
     const int r = b / RB_DW, c = b - r * RB_DW;
-    // clamped to the level's padded frame: a window that leaves it (edge threshold < 19) reads defined
-    // memory; inside the frame the clamps change nothing
-    const int gx = min(max(xw + 4 * c, -VO_PADX), pitch - VO_PADX - 4);
-    const uint8_t* col = blur + (size_t)f * s_g.pyr_bytes + s_g.lv[l].offset + (size_t)VO_PADY * pitch + VO_PADX + gx;
-    uint32_t wd[(RB_ROWS + 2) / 3];
+    // Thirteen rows per staging lane (rows r, r + 3, ...; the last only for r = 0).  A wave whose windows all lie
+    // inside their level's padded frame (always, at edge thresholds >= 19) addresses them by one 32-bit offset
+    // per lane from the frame's base and one addition per row; otherwise rows and columns are clamped to the
+    // frame, so that a window leaving it reads defined memory.
+    constexpr int NLD = (RB_ROWS + 2) / 3;
+    static_assert(3 * (NLD - 1) == RB_ROWS - 1, "the last step holds row r = 0 only");
+    const uint8_t* fb = blur + (size_t)f * s_g.pyr_bytes;
+    const bool inside = cy - RB_R >= -VO_PADY && cy + RB_R <= h + VO_PADY - 1 && xw >= -VO_PADX &&
+                        xw + 4 * RB_DW <= pitch - VO_PADX;
+    uint32_t wd[NLD] = {};
+    if (__builtin_amdgcn_ballot_w64(live && !inside) == 0) {
+        uint32_t off = s_g.lv[l].offset + (uint32_t)((VO_PADY + cy - RB_R + r) * pitch + VO_PADX + xw + 4 * c);
+        const uint32_t step = 3u * (uint32_t)pitch;
+        if (stage) {
 #pragma unroll
-    for (int i = 0; i < (RB_ROWS + 2) / 3; i++) {
-        const int row = r + 3 * i;
-        const int gy = min(max(cy - RB_R + row, -VO_PADY), h + VO_PADY - 1);
-        wd[i] = 0;
-        if (stage && row < RB_ROWS) wd[i] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch);
+            for (int i = 0; i < NLD - 1; i++, off += step) wd[i] = *reinterpret_cast<const uint32_t*>(fb + off);
+            if (r == 0) wd[NLD - 1] = *reinterpret_cast<const uint32_t*>(fb + off);
+        }
+    } else {
+        const int gx = min(max(xw + 4 * c, -VO_PADX), pitch - VO_PADX - 4);
+        const uint8_t* col = fb + s_g.lv[l].offset + (size_t)VO_PADY * pitch + VO_PADX + gx;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int row = r + 3 * i;
+            const int gy = min(max(cy - RB_R + row, -VO_PADY), h + VO_PADY - 1);
+            if (stage && row < RB_ROWS) wd[i] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch);
+        }
     }
     if (tid < RB_KP) {  // overlaps the window loads
         angle *= (float)(3.14159265358979323846 / 180.f);
