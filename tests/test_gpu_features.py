@@ -262,3 +262,23 @@ def test_orb_pyramid_and_blur_levels(vo, oracle, frames):
             assert g.shape == o.shape
             assert np.array_equal(g, o), "level %d %s: %d pixels differ" % (
                 level, "blur" if blurred else "pyramid", int((g != o).sum()))
+
+
+@pytest.mark.parametrize("scale,nlevels,w", [(2.0, 4, 1241), (1.5, 5, 1241), (1.1, 8, 1241), (1.2, 8, 1024), (1.2, 6, 337)])
+def test_orb_other_scale_factors_and_widths(vo, oracle, frames, scale, nlevels, w):
+    """Scale factors other than 1.2 size the resize kernel's LDS tile differently (2.0 needs more than the
+    default 64 KB of dynamic LDS), widths that are or are not multiples of 16 move the level-0 copy's chunk
+    boundaries: every pyramid level bit-exact, then keypoints and descriptors."""
+    from visual_odometry_amd import api
+
+    img = np.ascontiguousarray(frames[0][2][:, :w])
+    pg = api.orb_params(1500, scale_factor=scale, nlevels=nlevels)
+    po = oracle.orb_params(1500, scale_factor=scale, nlevels=nlevels)
+    kg, dg = vo.orb_detect_compute(img, pg)
+    for level in range(nlevels):
+        g = vo.debug_read_level(0, 0, level)
+        o = oracle.orb_level(img, po, level, blurred=False)
+        assert g.shape == o.shape and np.array_equal(g, o), "level %d" % level
+    ko, do = oracle.orb_detect_compute(img, po)
+    assert len(ko) > 300
+    assert np.array_equal(kg, ko) and np.array_equal(dg, do)
