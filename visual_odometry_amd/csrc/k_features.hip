@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
     if (VO_FAST_STOP == (n)) {                                                                    \
         unsigned acc_ = cntA[tid & 3] + cntB[tid & 3];  /* keep the phases' results alive */      \
         for (int i_ = tid; i_ < 4 * FT_LCAP; i_ += 256) acc_ += listA[i_];                        \
-        acc_ += sm[tid % SM_H][tid % SM_W];                                                       \
+        acc_ += sm[(tid % SM_H) * PX_W + tid % SM_W];                                             \
         if (acc_ == 0x12345678u) rowmask[0][0] = 1;                                               \
         __syncthreads();                                                                          \
         phase_e();                                                                                \
@@ -286,9 +286,12 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
                                                   int threshold, int border, int nms) {
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
-    __shared__ __attribute__((aligned(4))) uint8_t sm[SM_H][SM_W + 2];
+    // score map, rows PX_W apart like the pixel tile: pixel (sy, sx) of the score region is element
+    // sy * PX_W + sx of the map and has its ring centred on element (sy + 3) * PX_W + sx + 3 of the tile
+    __shared__ __attribute__((aligned(4))) uint8_t sm[SM_H * PX_W];
     // survivor / corner lists: one private region per wave (no atomics, no cross-wave ordering
-    // needed: the lists only feed the score map); entries are sy << 7 | sx.  The corner list of phase B
+    // needed: the lists only feed the score map); entries are that element index (< 2^13; bit 14 marks a dark
+    // arc), so no phase has to rebuild an LDS address from coordinates.  The corner list of phase B
     // is written over the survivor list it is compacted from: a step reads entries i0 .. i0 + 63 before
     // it writes, and writes below i0 + 64.
     __shared__ uint16_t listA[4 * FT_LCAP];
@@ -344,10 +347,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         for (int s = 0; s < STEPS; s++)
             if (act && r0 + RPS * s < PX_H) px4[tid + RW * RPS * s] = d[s];
     }
-    static_assert((SM_H * (SM_W + 2)) % 4 == 0, "score map is cleared in dwords");
+    static_assert((SM_H * PX_W) % 4 == 0, "score map is cleared in dwords");
     {
-        constexpr int SM_DW = SM_H * (SM_W + 2) / 4;
-        uint32_t* sm32 = reinterpret_cast<uint32_t*>(&sm[0][0]);
+        constexpr int SM_DW = SM_H * PX_W / 4;
+        uint32_t* sm32 = reinterpret_cast<uint32_t*>(&sm[0]);
 #pragma unroll
         for (int s = 0; s < SM_DW / 256; s++) sm32[tid + 256 * s] = 0;
         if (tid < SM_DW % 256) sm32[tid + 256 * (SM_DW / 256)] = 0;
@@ -375,56 +378,59 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
 
     // phase A: compass test.  Wave w takes the rows w, w + 4, ... of the score region with lane =
     // column; columns 64 and 65 of all rows are one more step for the last waves.
-    // Branch-free per row: the LDS reads are in range for every (sy, sx) of the score region, the
-    // image-border conditions are folded into the survivor mask, so that mask is the ballot itself.
+    // Branch-free per row: the LDS reads are in range for every (sy, sx) of the score region.
     int na = 0;  // survivors of this wave (wave-uniform)
     uint16_t* mineA = listA + wv * FT_LCAP;
+    constexpr int RING0 = 3 * PX_W + 3;  // from a pixel's element index to the centre of its ring in the tile
     {
-        // One compare decides a pixel: with mD = max(min(r0, r8), min(r4, r12)) and mB = min(max(r0, r8),
-        // max(r4, r12)), dark <=> mD < v - t and bright <=> mB > v + t, i.e. max(v - mD, mB - v) > t.  The
-        // image-border conditions go into the threshold (32767 where the pixel cannot be a corner: the
-        // column part once per lane, the row part wave-uniform), so the compare's mask is the ballot itself
-        // and no lane mask has to be rebuilt from scalar conditions.
-        // thr: the lane's threshold, 32767 where the pixel cannot be a corner (e never exceeds 510)
-        auto compass = [&](int sy, int sx, short thr) {
-            const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
-            // 16-bit arithmetic: two-operand 16-bit min / max issue in 2.3 cycles, 32-bit ones in 4.15
-            short v = c[0], r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
+        // As in the arc test below, one multiply-add per ring point tests it against both thresholds:
+        // P = (r - v + t) + ((v + t - r) << 16) = C - 65535 r with C = 65535 v + 65537 t has bit 15 set iff r is
+        // darker than v - t and bit 31 iff brighter than v + t.  A 9-arc holds two adjacent compass points, so
+        // the pixel survives iff S = (P0 | P8) & (P4 | P12) has one of the two bits.  The border conditions
+        // go into t (a threshold no difference reaches, 16000, where the pixel cannot be a corner: the column
+        // part once per lane, the row part wave-uniform), so no lane mask is rebuilt from scalar conditions.
+        auto compass = [&](int idx, uint32_t tt) {
+            const uint8_t* c = px + idx + RING0;
+            uint32_t v = c[0], r0 = c[3 * PX_W], r4 = c[3], r8 = c[-3 * PX_W], r12 = c[-3];
             // the five reads happen for every (sy, sx), outside any branch on the border conditions
             pin_loaded(v), pin_loaded(r0), pin_loaded(r4), pin_loaded(r8), pin_loaded(r12);
-            const short mD = max(min(r0, r8), min(r4, r12)), mB = min(max(r0, r8), max(r4, r12));
-            const short e = max((short)(v - mD), (short)(mB - v));
-            const bool surv = e > thr;
+            // (24-bit multiplies by name: behind pin_loaded the compiler no longer knows the values are bytes)
+            const uint32_t C = (uint32_t)__mul24((int)v, 65535) + tt;
+            auto P = [&](uint32_t r) { return C + (uint32_t)__mul24((int)r, -65535); };
+            const uint32_t S = (P(r0) | P(r8)) & (P(r4) | P(r12));
+            const bool surv = (S & 0x80008000u) != 0;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
             if (m) {
-                if (surv) mineA[na + mbcnt(m)] = (uint16_t)((sy << 7) | sx);
+                if (surv) mineA[na + mbcnt(m)] = (uint16_t)idx;
                 na += __popcll(m);
             }
         };
         // a pixel outside the detector region (keypoint rectangle + the ring the NMS reads) needs no score
         const int rx1 = L.rx0 + L.rw, ry1 = L.ry0 + L.rh;
-        auto border_thr = [&](int sy, int sx, bool in) {
+        auto border_tt = [&](int sy, int sx, bool in) {
             const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
-            short thr = (in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3) & (x >= L.rx0) & (x < rx1) &
-                         (y >= L.ry0) & (y < ry1))
-                            ? (short)threshold
-                            : (short)32767;
-            asm volatile("" : "+v"(thr));  // opaque: the compiler would turn it back into compare-and-mask
-            return thr;
+            uint32_t tt = (in & (x >= 3) & (x < w - 3) & (y >= 3) & (y < h - 3) & (x >= L.rx0) & (x < rx1) &
+                           (y >= L.ry0) & (y < ry1))
+                              ? (uint32_t)threshold * 65537u
+                              : 16000u * 65537u;
+            asm volatile("" : "+v"(tt));  // opaque: the compiler would turn it back into compare-and-mask
+            return tt;
         };
         {
             // rows outside the image or the region (wave-uniform) are skipped, the column condition is the
             // lane's threshold
             const int y_lo = max(3, L.ry0), y_hi = min(h - 3, ry1);  // y_lo <= y < y_hi
-            const short thr = border_thr(y_lo - (ty0 - 1), lane, true);
+            const uint32_t tt = border_tt(y_lo - (ty0 - 1), lane, true);
             const int sy_lo = y_lo - (ty0 - 1), sy_hi = min(y_hi - (ty0 - 1), SM_H);
-            for (int sy = wv + 4 * (max(sy_lo - wv + 3, 0) >> 2); sy < sy_hi; sy += 4) compass(sy, lane, thr);
+            const int sy0 = wv + 4 * (max(sy_lo - wv + 3, 0) >> 2);
+            int idx = sy0 * PX_W + lane;
+            for (int sy = sy0; sy < sy_hi; sy += 4, idx += 4 * PX_W) compass(idx, tt);
         }
         static_assert(2 * SM_H <= 3 * 64, "columns 64 and 65 fit one step of waves 3, 2, 1");
         if ((3 - wv) * 64 < 2 * SM_H) {
             const int q = (3 - wv) * 64 + lane;  // 0 .. 2 * SM_H - 1
             const int sy = min(q >> 1, SM_H - 1), sx = FT_W + (q & 1);
-            compass(sy, sx, border_thr(sy, sx, q < 2 * SM_H));
+            compass(sy * PX_W + sx, border_tt(sy, sx, q < 2 * SM_H));
         }
     }
     wave_lds_sync();
@@ -444,8 +450,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
             int p = 0;
             if (i < na) {
                 p = mineA[i];
-                const int sy = p >> 7, sx = p & 127;
-                const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+                const uint8_t* c = px + p + RING0;
                 const uint32_t tt = (uint32_t)threshold * 65537u;
                 // One multiply-add per ring point gives both tests: P = (r - v + t) + ((v + t - r) << 16) has bit 15
                 // set iff r < v - t (dark) and bit 31 set iff r > v + t (bright) -- the fields stay within 16 bits
@@ -488,9 +493,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     // need a second 9-arc), so one min network on e = +-d is enough: the same score.
     // Each wave scores its own corners; the block meets only afterwards, when the NMS needs the whole map.
     for (int i = lane; i < nb_w; i += 64) {
-        const int p = mineB[i];
-        const int sy = (p >> 7) & 127, sx = p & 127;
-        const uint8_t* c = px + (sy + 3) * PX_W + (sx + 3);
+        const int p = mineB[i], idx = p & 0x1fff;
+        const uint8_t* c = px + idx + RING0;
         // e = v - ring for a dark arc, ring - v for a bright one: one multiply-add per point
         const int nsgn = (p & 0x4000) ? -1 : 1;
         const int sv = -nsgn * (int)c[0];
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
         for (int k = 0; k < 16; k++) m9[k] = min3i(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
 #pragma unroll
         for (int k = 0; k < 16; k += 2) best = max3i(best, m9[k], m9[k + 1]);
-        sm[sy][sx] = (uint8_t)best;  // (best - 1) + 1
+        sm[idx] = (uint8_t)best;  // (best - 1) + 1
     }
     __syncthreads();
     VO_FAST_PHASE_END(3);
@@ -520,20 +524,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const bool level_ok = border == 0 || (w > 2 * border && h > 2 * border);
     uint8_t* sc = level_px(score, g, f, l);
     for (int i = lane; i < nb_w; i += 64) {
-        const int p = mineB[i];
-        const int sy = (p >> 7) & 127, sx = p & 127;
+        const int idx = mineB[i] & 0x1fff;
+        static_assert(SM_H * PX_W * 3641ull < (1ull << 32) && PX_W == 72, "idx / 72 by multiplication");
+        const int sy = (int)(__umul24(idx, 3641) >> 18), sx = idx - sy * PX_W;
         const int x = tx0 - 1 + sx, y = ty0 - 1 + sy;
         const bool in = (sx >= 1) & (sx <= FT_W) & (sy >= 1) & (sy <= FT_H) & level_ok & (x >= b) & (x < w - b) &
                         (y >= b) & (y < h - b);
         if (!in) continue;
-        const uint8_t* q = &sm[sy][sx];
+        const uint8_t* q = &sm[idx];
         const int s1 = q[0];
         bool kp = true;
         if (nms) {
             // The map holds score + 1 (0 = not a corner); cv keeps a corner whose score exceeds the scores of
             // its eight neighbours, a neighbour that is not a corner counting as 0: s1 - 1 > (q ? q - 1 : 0)
             // for all eight, i.e. s1 > max(1, the eight map values).
-            constexpr int SP = SM_W + 2;
+            constexpr int SP = PX_W;
             const int a0 = q[-SP - 1], a1 = q[-SP], a2 = q[-SP + 1], a3 = q[-1], a4 = q[1], a5 = q[SP - 1], a6 = q[SP],
                       a7 = q[SP + 1];
             kp = s1 > max(max(max(max(a0, a1), a2), max(max(a3, a4), a5)), max(max(a6, a7), 1));
