@@ -282,9 +282,14 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, R
 // entries of a wave's list: its rows of phase A (every fourth of the score region) x 64 + one more step
 #define FT_LCAP (((SM_H + 3) / 4) * 64 + 64)
 
+struct FastTiles {  // first tile of every level, by value: the level of a block is found without a load
+    int nlevels;
+    int tile0[VO_ORB_MAX_LEVELS];
+};
+
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
-                                                  int threshold, int border, int nms) {
+                                                  int threshold, int border, int nms, FastTiles ft) {
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
     // score map, rows PX_W apart like the pixel tile: pixel (sy, sx) of the score region is element
     // sy * PX_W + sx of the map and has its ring centred on element (sy + 3) * PX_W + sx + 3 of the tile
@@ -303,8 +308,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ py
     const uint8_t* px = reinterpret_cast<const uint8_t*>(px4);
     const int f = blockIdx.y, tid = threadIdx.x;
     int l = 0;
-    for (int i = 1; i < g->nlevels; i++)
-        if ((int)blockIdx.x >= g->lv[i].tile0) l = i;
+#pragma unroll
+    for (int i = 1; i < VO_ORB_MAX_LEVELS; i++)
+        if (i < ft.nlevels && (int)blockIdx.x >= ft.tile0[i]) l = i;
     const LevelGeom L = g->lv[l];
     const int local = blockIdx.x - L.tile0;
     const int tix = local % L.tiles_x, tiy = local / L.tiles_x;
@@ -1489,7 +1495,10 @@ void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, c
                      unsigned long long* masks, int threshold, int border, int nms, int nframes) {
     if (hg.tiles_total == 0) return;
     dim3 grid(hg.tiles_total, nframes);
-    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms);
+    FastTiles ft = {};
+    ft.nlevels = hg.nlevels;
+    for (int i = 0; i < hg.nlevels; i++) ft.tile0[i] = hg.lv[i].tile0;
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms, ft);
 }
 
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
