@@ -1289,16 +1289,21 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
         }
         if (k >= 3) {
             const int yo = y0 + 2 * (k - 3);
-            uint32_t oe = 0, oo = 0;
+            uint32_t ae[4], ao[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t ae =
-                    udot2(P[0][j], E0, udot2(P[1][j], E1, udot2(P[2][j], E2, udot2(P[3][j], E3, 1u << 15))));
-                const uint32_t ao =
-                    udot2(P[0][j], O0, udot2(P[1][j], O1, udot2(P[2][j], O2, udot2(P[3][j], O3, 1u << 15))));
-                oe |= min(ae >> 16, 255u) << (8 * j);
-                oo |= min(ao >> 16, 255u) << (8 * j);
+                ae[j] = udot2(P[0][j], E0, udot2(P[1][j], E1, udot2(P[2][j], E2, udot2(P[3][j], E3, 1u << 15))));
+                ao[j] = udot2(P[0][j], O0, udot2(P[1][j], O1, udot2(P[2][j], O2, udot2(P[3][j], O3, 1u << 15))));
             }
+            // the taps sum to 257, so a sum can reach 257 << 16: the high halves of two sums side by side
+            // (one byte permute), saturated to bytes by v_sat_pk_u8_i16, two of those joined by another permute
+            auto pack4 = [](const uint32_t (&a)[4]) {
+                uint32_t lo, hi;
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(__builtin_amdgcn_perm(a[1], a[0], 0x07060302u)));
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(__builtin_amdgcn_perm(a[3], a[2], 0x07060302u)));
+                return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            };
+            const uint32_t oe = pack4(ae), oo = pack4(ao);
             if (yo < h) *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)yo * pitch) = oe;
             if (yo + 1 < h) *reinterpret_cast<uint32_t*>(dst + (ptrdiff_t)(yo + 1) * pitch) = oo;
         }
