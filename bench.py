@@ -450,6 +450,21 @@ def main():
                     "bound": "hbm", "achieved": feat_bytes / feat_s / 1e9 if feat_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": feat_bytes / feat_s / 1e9 / HBM_PEAK_GBS if feat_s > 0 else 0.0,
                     "algorithmic_bytes_per_batch": feat_bytes, "avg_batch_us": feat_s * 1e6}
+        # the stage's largest kernel against what bounds IT: vector-instruction issue (one wave64 instruction
+        # per SIMD every 4 cycles); instruction count from the committed SQ pass, duration live from HIP events
+        try:
+            with open(os.path.join(ROOT, "profiles", "sq_latest.json")) as fh:
+                sqj = json.load(fh)
+            fast_insts = float(sqj["kernels"]["k_fast_nms"]["SQ_INSTS_VALU"])
+            fast_s = fast_ms / max(fast_n, 1) * 1e-3
+            peak = 1024 * 2.4e9 / 4  # wave instructions per second over the chip's 1 024 SIMDs at 2.4 GHz
+            detector["fast_nms"] = {"bound": "valu", "achieved": fast_insts / fast_s / 1e9 if fast_s > 0 else None,
+                                    "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                                    "frac": fast_insts / fast_s / peak if fast_s > 0 else None,
+                                    "vector_instructions_per_launch": fast_insts, "avg_launch_us": fast_s * 1e6,
+                                    "source": "profiles/%s_sq.json" % sqj.get("tag", "?")}
+        except (OSError, KeyError, ValueError):
+            detector["fast_nms"] = None
 
         # ---- the same sequence with the frames in pinned host memory: every chunk crosses PCIe inside the
         # timed region (its copy overlaps the kernels of the other chunks).  Beside `value`, never as it.

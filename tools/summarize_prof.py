@@ -5,6 +5,7 @@ committed summaries under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
   profiles/<tag>_pmc.json           per kernel: launches, mean FETCH_SIZE / WRITE_SIZE bytes per launch
   profiles/pmc_latest.json          copy of the newest <tag>_pmc.json (bench.py reads `traffic` here)
+  profiles/<tag>_sq.json, sq_latest.json   SQ counters per kernel (bench.py reads FAST's instruction count here)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts a 128-byte
 request of a wide (16 B per lane) streaming read as 64 bytes (MI355X_MICROARCH.md, HBM); kernels
@@ -75,6 +76,7 @@ def main():
                                   "summed over all waves, SQ_BUSY_CYCLES is summed over the 32 shader engines",
               "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(agg.items())}}
         json.dump(sq, open(os.path.join(dst, tag + "_sq.json"), "w"), indent=1)
+        shutil.copy(os.path.join(dst, tag + "_sq.json"), os.path.join(dst, "sq_latest.json"))  # bench.py reads it
         for k in ("k_knn2<8>", "k_fast_nms"):
             if k in sq["kernels"]:
                 print(k, {c: round(v) for c, v in sq["kernels"][k].items()})
