@@ -37,6 +37,21 @@ def test_fast_noise_sizes(vo, oracle, h, w, thr):
     assert np.array_equal(g, o)
 
 
+@pytest.mark.parametrize("thr", [200, 254, 255, 300])
+def test_fast_threshold_extremes(vo, oracle, thr):
+    """Black / white blocks with isolated pixels: differences of exactly 255 exist, so thresholds up to 254 still
+    find corners, 255 finds none, and a threshold beyond the byte range is clamped to 255 as cv does.  The
+    kernel's packed two-field test (r - v + t | v + t - r << 16) has its largest fields here."""
+    rng = np.random.default_rng(thr)
+    img = (rng.integers(0, 2, (90, 160)) * 255).astype(np.uint8)
+    img = np.kron(img[::3, ::4], np.ones((3, 4), np.uint8))[:90, :160].copy()
+    img[rng.integers(0, 90, 300), rng.integers(0, 160, 300)] ^= 255
+    g = vo.fast_detect(img, thr, True, cap=90 * 160)
+    o = oracle.fast_detect(img, min(thr, 255), True)
+    assert np.array_equal(g, o)
+    assert (len(o) > 0) == (thr < 255)
+
+
 def test_fast_without_nms(vo, oracle):
     img = _noise(120, 200, 9, smooth=True)
     g = vo.fast_detect(img, 20, False, cap=120 * 200)
