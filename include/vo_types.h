@@ -92,6 +92,10 @@ typedef struct vo_lk_params {
 #define VO_ERR_FAILED 4     /* the estimator found no model (cv returns an empty Mat) */
 
 #define VO_ORB_MAX_LEVELS 16
+/* Smallest edge_threshold accepted: the descriptor window reaches 18 pixels from a keypoint, so below 19 it
+ * would leave the image (cv pads every level by more than that and reads reflected pixels there; this
+ * library keeps a 3-pixel frame only and refuses instead). The reference never changes the default, 31. */
+#define VO_ORB_MIN_EDGE 19
 #define VO_DESC_BYTES 32
 
 #ifdef __cplusplus

@@ -297,3 +297,34 @@ def test_orb_other_scale_factors_and_widths(vo, oracle, frames, scale, nlevels, 
     ko, do = oracle.orb_detect_compute(img, po)
     assert len(ko) > 300
     assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+
+
+def test_orb_edge_threshold_below_the_window_radius_is_refused(vo, frames):
+    """Keypoints closer than 19 pixels to the border would have their descriptor window outside the image."""
+    from visual_odometry_amd import api
+    from visual_odometry_amd.api import VoError
+
+    for edge in (0, 8, 18):
+        with pytest.raises(VoError) as e:
+            vo.orb_detect_compute(frames[0][1], api.orb_params(500, edge_threshold=edge))
+        assert e.value.code == 1
+    assert len(vo.orb_detect_compute(frames[0][1], api.orb_params(500, edge_threshold=19))[0]) > 400
+
+
+@pytest.mark.parametrize("edge", [31, 19])
+def test_orb_fused_orientation_description_equals_the_two_kernels(vo, oracle, frames, edge, monkeypatch):
+    """The detection path computes the IC angle and the rBRIEF descriptor in one kernel (k_orient_rbrief);
+    VO_ORB_SPLIT=1 runs k_ic_angle and k_rbrief apart.  Same keypoints (angle included), same descriptors, both
+    equal to the oracle, at the default border and at the smallest one accepted."""
+    from visual_odometry_amd import api
+
+    img = frames[0][1]
+    pg = api.orb_params(2000, edge_threshold=edge)
+    monkeypatch.setenv("VO_ORB_SPLIT", "1")
+    ks, ds = vo.orb_detect_compute(img, pg)
+    monkeypatch.delenv("VO_ORB_SPLIT")
+    kf, df = vo.orb_detect_compute(img, pg)
+    assert len(kf) > 1500
+    assert np.array_equal(kf, ks) and np.array_equal(df, ds)
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(2000, edge_threshold=edge))
+    assert np.array_equal(kf, ko) and np.array_equal(df, do)

@@ -1459,6 +1459,195 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ic_angle and k_rbrief in one kernel, for the detection path (the blurred pyramid is made before it).
+// Both give a keypoint 32 lanes -- patch row / descriptor byte -- so the block keeps k_rbrief's shape and a
+// group first does k_ic_angle's work: candidate -> nine patch dwords and nine mask dwords per lane, with the
+// 37 x 37 window of the blurred level requested in the same batch (it depends on the position only, not on
+// the angle), moments by dot products and DPP sums, the angle on the group's first lane.  What the separate
+// kernels paid for twice -- count -> candidate -> geometry -> pixels, one wave lifetime each -- and the trip
+// of the keypoint record through memory between them happen once.  Same arithmetic, same results.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                       const PyrGeom* __restrict__ g, const Cand* __restrict__ sel,
+                                                       const int* __restrict__ flags, int max_cand,
+                                                       const Cand* __restrict__ selcand, const int* __restrict__ selcnt,
+                                                       const int* __restrict__ lvlofs, const int* __restrict__ nkp,
+                                                       int kp_cap, vo_keypoint* __restrict__ out,
+                                                       uint8_t* __restrict__ desc) {
+    __shared__ __attribute__((aligned(16))) float patf[1024];
+    __shared__ uint32_t win[RB_KP][RB_ROWS * RB_DW];
+    __shared__ float s_ang[RB_KP], s_ca[RB_KP], s_sa[RB_KP];
+    const int tid = threadIdx.x;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int n = nkp[f];
+    int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
+    {
+        const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
+        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+            cnt[i] = sc[i];
+            ofs[i] = lo[i];
+        }
+    }
+    const int k0 = bx * RB_KP;
+    if (k0 >= n) return;  // the whole block
+    const int slot = tid >> 5, b = tid & 31, k = min(k0 + slot, n - 1);
+    const bool live = k0 + slot < n;
+    const uint32_t q = reinterpret_cast<const uint32_t*>(c_orb_pattern)[tid];
+    Cand cd;
+    int lg;
+    // sel != NULL: the frames flagged in `flags` take their keypoints from the host selection
+    if (sel && flags[f] != 0) {
+        cd = sel[(size_t)f * kp_cap + k];
+        lg = cd.level;
+    } else {
+        const int nl = g->nlevels;
+        int l = 0, rem = k, base = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++)
+            if (!found && i < nl) {
+                if (rem < cnt[i]) {
+                    found = true;
+                    l = i;
+                    base = ofs[i];
+                } else {
+                    rem -= cnt[i];
+                }
+            }
+        if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
+        lg = l;
+        cd = selcand[(size_t)f * max_cand + base + rem];
+    }
+    {
+        float4 v;
+        v.x = (float)(int8_t)(q & 0xff);
+        v.y = (float)(int8_t)((q >> 8) & 0xff);
+        v.z = (float)(int8_t)((q >> 16) & 0xff);
+        v.w = (float)(int8_t)(q >> 24);
+        reinterpret_cast<float4*>(patf)[tid] = v;
+    }
+    const int pitch = g->lv[lg].pitch, h = g->lv[lg].h;
+    const unsigned lofs = g->lv[lg].offset;
+    const float lscale = g->lv[lg].scale;
+    const size_t fofs = (size_t)f * g->pyr_bytes;
+    // --- orientation: the lane's patch row
+    const int r = min(b, 30), v = r - 15;
+    uint32_t dw[9], mk[9];
+    int oi;
+    {
+        const int xw = (cd.x - 15) & ~3;
+        oi = (cd.x - 15) - xw;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(pyr + fofs + lofs +
+                                                                (size_t)__mul24(VO_PADY + cd.y + v, pitch) + VO_PADX + xw);
+        const uint32_t* msk = c_ic_masks.m[v < 0 ? -v : v][oi];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            dw[i] = row[i];
+            mk[i] = msk[i];
+        }
+    }
+    // --- description: the lane's rows of the blurred window, as in k_rbrief
+    vo_keypoint kp;
+    kp.x = (float)cd.x * lscale;
+    kp.y = (float)cd.y * lscale;
+    kp.size = 31 * lscale;
+    kp.response = cd.harris;
+    kp.octave = cd.level;
+    kp.class_id = -1;
+    const float scale = 1.f / lscale;
+    const int cy = __float2int_rn(kp.y * scale), cx = __float2int_rn(kp.x * scale);
+    const int xw = (cx - RB_R) & ~3, o = cx - RB_R - xw;
+    const bool stage = live && b < 3 * RB_DW;
+    const int rr = b / RB_DW, c = b - rr * RB_DW;
+    constexpr int NLD = (RB_ROWS + 2) / 3;
+    const uint8_t* fb = blur + fofs;
+    const bool inside = cy - RB_R >= -VO_PADY && cy + RB_R <= h + VO_PADY - 1 && xw >= -VO_PADX &&
+                        xw + 4 * RB_DW <= pitch - VO_PADX;
+    uint32_t wd[NLD] = {};
+    if (__builtin_amdgcn_ballot_w64(live && !inside) == 0) {
+        uint32_t off = lofs + (uint32_t)((VO_PADY + cy - RB_R + rr) * pitch + VO_PADX + xw + 4 * c);
+        const uint32_t step = 3u * (uint32_t)pitch;
+        if (stage) {
+#pragma unroll
+            for (int i = 0; i < NLD - 1; i++, off += step) wd[i] = *reinterpret_cast<const uint32_t*>(fb + off);
+            if (rr == 0) wd[NLD - 1] = *reinterpret_cast<const uint32_t*>(fb + off);
+        }
+    } else {
+        const int gx = min(max(xw + 4 * c, -VO_PADX), pitch - VO_PADX - 4);
+        const uint8_t* col = fb + lofs + (size_t)VO_PADY * pitch + VO_PADX + gx;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int row = rr + 3 * i;
+            const int gy = min(max(cy - RB_R + row, -VO_PADY), h + VO_PADY - 1);
+            if (stage && row < RB_ROWS) wd[i] = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch);
+        }
+    }
+    // --- moments and angle (k_ic_angle's arithmetic)
+    {
+        uint32_t sb = 0, sw = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const uint32_t d = dw[i] & mk[i];
+            sb = __builtin_amdgcn_udot4(d, 0x01010101u, sb, false);
+            sw = __builtin_amdgcn_udot4(d, 0x03020100u + 0x04040404u * i, sw, false);
+        }
+        int m10 = (int)sw - __mul24(15 + oi, (int)sb), m01 = __mul24(v, (int)sb);
+        if (!live || b == 31) m10 = m01 = 0;
+        m10 = row16_sum(m10);
+        m01 = row16_sum(m01);
+        // halves of the wave: rows 0-1 and rows 2-3
+        const int a10 = __builtin_amdgcn_readlane(m10, 0) + __builtin_amdgcn_readlane(m10, 16);
+        const int b10 = __builtin_amdgcn_readlane(m10, 32) + __builtin_amdgcn_readlane(m10, 48);
+        const int a01 = __builtin_amdgcn_readlane(m01, 0) + __builtin_amdgcn_readlane(m01, 16);
+        const int b01 = __builtin_amdgcn_readlane(m01, 32) + __builtin_amdgcn_readlane(m01, 48);
+        if (b == 0) {
+            const bool hi = (tid & 32) != 0;
+            kp.angle = live ? fast_atan2_deg((float)(hi ? b01 : a01), (float)(hi ? b10 : a10)) : 0.f;
+            s_ang[slot] = kp.angle;
+            if (live) out[(size_t)f * kp_cap + k] = kp;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+        const int row = rr + 3 * i;
+        if (stage && row < RB_ROWS) win[slot][row * RB_DW + c] = wd[i];
+    }
+    __syncthreads();
+    if (tid < RB_KP) {
+        float angle = s_ang[tid];
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        sincos_2pi((double)angle, s_ca[tid], s_sa[tid]);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float ca = s_ca[slot], sa = s_sa[slot];
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+    constexpr float MAGIC = 12582912.f;
+    constexpr uint32_t MAGIC_K = 0x4B400000u + (uint32_t)(4 * RB_DW) * 0x400000u;
+    const uint32_t center = (uint32_t)(uintptr_t)(lds_u8*)(reinterpret_cast<const uint8_t*>(win[slot]) +
+                                                           RB_R * (4 * RB_DW) + RB_R + o) - MAGIC_K;
+    const float2* p = reinterpret_cast<const float2*>(patf) + b * 16;
+    int val = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        int vv[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float2 pt = p[2 * t + e];
+            const float x = pt.x * ca - pt.y * sa;
+            const float y = pt.x * sa + pt.y * ca;
+            const int at = __mul24(__builtin_bit_cast(int, y + MAGIC), 4 * RB_DW) + __builtin_bit_cast(int, x + MAGIC);
+            vv[e] = *(lds_u8*)(uintptr_t)(center + (uint32_t)at);
+        }
+        val |= (vv[0] < vv[1]) << t;
+    }
+    desc[((size_t)f * kp_cap + k) * 32 + b] = (uint8_t)val;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, int stride, const PyrGeom* d_geom,
@@ -1564,4 +1753,14 @@ void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, c
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, 8), nframes);
     hipLaunchKernelGGL(k_rbrief, grid, dim3(256), 0, st, d_geom, blur, kps, nkp, kp_cap, desc);
+}
+
+void launch_orient_rbrief(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, const PyrGeom* d_geom,
+                          const Cand* sel, const int* flags, int max_cand, const Cand* selcand, const int* selcnt,
+                          const int* lvlofs, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
+                          int nframes) {
+    if (max_n <= 0) return;
+    dim3 grid(cdiv(max_n, RB_KP), nframes);
+    hipLaunchKernelGGL(k_orient_rbrief, grid, dim3(256), 0, st, pyr, blur, d_geom, sel, flags, max_cand, selcand,
+                       selcnt, lvlofs, nkp, kp_cap, out, desc);
 }

@@ -22,7 +22,7 @@ inline int cv_floor(double v) {
 bool orb_params_ok(const vo_orb_params* p) {
     return p && p->nfeatures >= 0 && p->nlevels >= 1 && p->nlevels <= VO_ORB_MAX_LEVELS &&
            p->first_level == 0 && p->wta_k == 2 && p->score_type == 0 && p->patch_size == 31 &&
-           p->scale_factor > 1.0f && p->edge_threshold >= 0 && p->fast_threshold >= 0;
+           p->scale_factor > 1.0f && p->edge_threshold >= VO_ORB_MIN_EDGE && p->fast_threshold >= 0;
 }
 
 // interpolationLinear<uchar>::getCoeffs of cv's bit-exact resize: entry = ofs << 16 | c1
@@ -96,6 +96,9 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     const int nlevels = p ? p->nlevels : 1;
     const float sf = p ? p->scale_factor : 1.2f;
     const int nfeatures = p ? p->nfeatures : 0;
+    // every path that describes keypoints comes through here: the orientation patch (radius 15) and the
+    // descriptor window (radius 18) are read without clamping, which the edge threshold has to allow
+    if (p && !orb_params_ok(p)) return c->fail(VO_ERR_INVALID, "unsupported ORB parameters");
     if (w < 7 || h < 7) return c->fail(VO_ERR_INVALID, "image %dx%d is smaller than the FAST ring", w, h);
     if (w > c->lim.max_width || h > c->lim.max_height)
         return c->fail(VO_ERR_CAPACITY, "image %dx%d exceeds the context limits %dx%d", w, h,
@@ -402,14 +405,24 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     static const Taps7 taps = gauss_taps();
     const PyrGeom& g = c->geom;
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
+    // host_selection = the redo of a batch whose first pass already blurred the pyramid
+    if (!host_selection)
+        launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
+    const char* split_env = getenv("VO_ORB_SPLIT");  // 1: orientation and description as two kernels (read per call)
+    const bool split = split_env && atoi(split_env) != 0;
+    if (angles && !split) {
+        launch_orient_rbrief(c->stream, c->d_pyr.as<uint8_t>(), c->d_blur.as<uint8_t>(), dg,
+                             host_selection ? c->d_sel.as<Cand>() : nullptr, c->d_flags.as<int>(), c->max_cand,
+                             c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(), c->d_lvlofs.as<int>(),
+                             c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
+                             c->d_desc.as<uint8_t>(), nframes);
+        return vo_check_launch(c, "feature description");
+    }
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
                         c->d_flags.as<int>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
                         c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                         nframes);
-    // host_selection = the redo of a batch whose first pass already blurred the pyramid
-    if (!host_selection)
-        launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
     launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
                   c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
     return vo_check_launch(c, "feature description");
