@@ -1383,7 +1383,10 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
         v.y = (float)(int8_t)((q >> 8) & 0xff);
         v.z = (float)(int8_t)((q >> 16) & 0xff);
         v.w = (float)(int8_t)(q >> 24);
-        reinterpret_cast<float4*>(patf)[tid] = v;
+        // float4 tid = pattern points 2 tid, 2 tid + 1 = pair (tid & 7) of descriptor byte tid >> 3; stored
+        // pair-major so that the 32 lanes of a group read consecutive 16-byte slots (byte-major, every lane's
+        // slot started 128 bytes after its neighbour's: all in the same four banks, a 32-way conflict per read)
+        reinterpret_cast<float4*>(patf)[(tid & 7) * 32 + (tid >> 3)] = v;
     }
     __syncthreads();
     const int l = kp.octave;
@@ -1440,14 +1443,15 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
     constexpr uint32_t MAGIC_K = 0x4B400000u + (uint32_t)(4 * RB_DW) * 0x400000u;
     const uint32_t center = (uint32_t)(uintptr_t)(lds_u8*)(reinterpret_cast<const uint8_t*>(win[slot]) +
                                                            RB_R * (4 * RB_DW) + RB_R + o) - MAGIC_K;
-    const float2* p = reinterpret_cast<const float2*>(patf) + b * 16;
+    const float4* p = reinterpret_cast<const float4*>(patf) + b;
     int val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         int v[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float2 pt = p[2 * t + e];
+            const float4 pp = p[32 * t];
+            const float2 pt = e ? make_float2(pp.z, pp.w) : make_float2(pp.x, pp.y);
             const float x = pt.x * ca - pt.y * sa;
             const float y = pt.x * sa + pt.y * ca;
             const int at = __mul24(__builtin_bit_cast(int, y + MAGIC), 4 * RB_DW) + __builtin_bit_cast(int, x + MAGIC);
@@ -1476,7 +1480,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
                                                        uint8_t* __restrict__ desc) {
     __shared__ __attribute__((aligned(16))) float patf[1024];
     __shared__ uint32_t win[RB_KP][RB_ROWS * RB_DW];
-    __shared__ float s_ang[RB_KP], s_ca[RB_KP], s_sa[RB_KP];
+    __shared__ float s_m01[RB_KP], s_m10[RB_KP], s_ca[RB_KP], s_sa[RB_KP];
     const int tid = threadIdx.x;
     int bx, f;
     xcd_frame_block(bx, f);
@@ -1507,8 +1511,9 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
         int l = 0, rem = k, base = 0;
         bool found = false;
 #pragma unroll
-        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++)
-            if (!found && i < nl) {
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+            if (i >= nl) break;  // uniform: half the table is unused at eight levels
+            if (!found) {
                 if (rem < cnt[i]) {
                     found = true;
                     l = i;
@@ -1517,6 +1522,7 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
                     rem -= cnt[i];
                 }
             }
+        }
         if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
         lg = l;
         cd = selcand[(size_t)f * max_cand + base + rem];
@@ -1527,7 +1533,10 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
         v.y = (float)(int8_t)((q >> 8) & 0xff);
         v.z = (float)(int8_t)((q >> 16) & 0xff);
         v.w = (float)(int8_t)(q >> 24);
-        reinterpret_cast<float4*>(patf)[tid] = v;
+        // float4 tid = pattern points 2 tid, 2 tid + 1 = pair (tid & 7) of descriptor byte tid >> 3; stored
+        // pair-major so that the 32 lanes of a group read consecutive 16-byte slots (byte-major, every lane's
+        // slot started 128 bytes after its neighbour's: all in the same four banks, a 32-way conflict per read)
+        reinterpret_cast<float4*>(patf)[(tid & 7) * 32 + (tid >> 3)] = v;
     }
     const int pitch = g->lv[lg].pitch, h = g->lv[lg].h;
     const unsigned lofs = g->lv[lg].offset;
@@ -1603,10 +1612,13 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
         const int b10 = __builtin_amdgcn_readlane(m10, 32) + __builtin_amdgcn_readlane(m10, 48);
         const int a01 = __builtin_amdgcn_readlane(m01, 0) + __builtin_amdgcn_readlane(m01, 16);
         const int b01 = __builtin_amdgcn_readlane(m01, 32) + __builtin_amdgcn_readlane(m01, 48);
+        // the group's first lane stores the keypoint without its angle and hands the moments to the block's
+        // first lanes, which take atan2 and cos / sin for all eight keypoints at once after the barrier
         if (b == 0) {
             const bool hi = (tid & 32) != 0;
-            kp.angle = live ? fast_atan2_deg((float)(hi ? b01 : a01), (float)(hi ? b10 : a10)) : 0.f;
-            s_ang[slot] = kp.angle;
+            s_m01[slot] = (float)(hi ? b01 : a01);
+            s_m10[slot] = (float)(hi ? b10 : a10);
+            kp.angle = 0.f;
             if (live) out[(size_t)f * kp_cap + k] = kp;
         }
     }
@@ -1617,7 +1629,8 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
     }
     __syncthreads();
     if (tid < RB_KP) {
-        float angle = s_ang[tid];
+        float angle = fast_atan2_deg(s_m01[tid], s_m10[tid]);
+        if (k0 + tid < n) out[(size_t)f * kp_cap + k0 + tid].angle = angle;
         angle *= (float)(3.14159265358979323846 / 180.f);
         sincos_2pi((double)angle, s_ca[tid], s_sa[tid]);
     }
@@ -1629,14 +1642,15 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
     constexpr uint32_t MAGIC_K = 0x4B400000u + (uint32_t)(4 * RB_DW) * 0x400000u;
     const uint32_t center = (uint32_t)(uintptr_t)(lds_u8*)(reinterpret_cast<const uint8_t*>(win[slot]) +
                                                            RB_R * (4 * RB_DW) + RB_R + o) - MAGIC_K;
-    const float2* p = reinterpret_cast<const float2*>(patf) + b * 16;
+    const float4* p = reinterpret_cast<const float4*>(patf) + b;
     int val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         int vv[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            const float2 pt = p[2 * t + e];
+            const float4 pp = p[32 * t];
+            const float2 pt = e ? make_float2(pp.z, pp.w) : make_float2(pp.x, pp.y);
             const float x = pt.x * ca - pt.y * sa;
             const float y = pt.x * sa + pt.y * ca;
             const int at = __mul24(__builtin_bit_cast(int, y + MAGIC), 4 * RB_DW) + __builtin_bit_cast(int, x + MAGIC);
