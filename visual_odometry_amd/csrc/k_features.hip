@@ -1261,10 +1261,16 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
     // column taps for an even output row (input rows 2m .. 2m+6) and an odd one (2m+1 .. 2m+7)
     const uint32_t E0 = t0 | (t1 << 16), E1 = t2 | (t3 << 16), E2 = t4 | (t5 << 16), E3 = t6;
     const uint32_t O0 = t0 << 16, O1 = t1 | (t2 << 16), O2 = t3 | (t4 << 16), O3 = t5 | (t6 << 16);
-    auto row_sums = [&](int r, uint32_t (&H)[4]) {
+    // the three dwords of input row r (12-byte window A B C), and the row sums of the four pixels from them;
+    // the loads of the next two row pairs are issued before the sums of the current one are taken: a wave has
+    // one short dependent step per pair otherwise and runs at memory latency
+    auto row_load = [&](int r, uint32_t (&W)[3]) {
         const int y = min(y0 - 3 + r, h + 2);
         const uint32_t* row = reinterpret_cast<const uint32_t*>(src + (ptrdiff_t)y * pitch);
-        const uint32_t A = row[-1], B = row[0], C = row[1];
+        W[0] = row[-1], W[1] = row[0], W[2] = row[1];
+    };
+    auto row_sums = [&](const uint32_t (&W)[3], uint32_t (&H)[4]) {
+        const uint32_t A = W[0], B = W[1], C = W[2];
         // pixel j sums bytes 1+j .. 7+j of the 12-byte window A B C
         H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), TA,
                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), TB, 0, false), false);
@@ -1274,12 +1280,25 @@ __global__ __launch_bounds__(256) void k_gauss7(const uint8_t* __restrict__ pyr,
                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), TB, 0, false), false);
         H[3] = __builtin_amdgcn_udot4(B, TA, __builtin_amdgcn_udot4(C, TB, 0, false), false);
     };
+    constexpr int NK = (GB_ROWS + 6) / 2, AHEAD = 2;
+    uint32_t W[NK + AHEAD][2][3];
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+        row_load(2 * k, W[k][0]);
+        row_load(2 * k + 1, W[k][1]);
+    }
     uint32_t P[4][4] = {};  // the last four (even, odd) pairs of row sums, per pixel
 #pragma unroll
-    for (int k = 0; k < (GB_ROWS + 6) / 2; k++) {
+    for (int k = 0; k < NK; k++) {
+        if (k + AHEAD < NK) {
+            row_load(2 * (k + AHEAD), W[k + AHEAD][0]);
+            row_load(2 * (k + AHEAD) + 1, W[k + AHEAD][1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) pin_loaded(W[k][0][u]), pin_loaded(W[k][1][u]);
         uint32_t He[4], Ho[4];
-        row_sums(2 * k, He);
-        row_sums(2 * k + 1, Ho);
+        row_sums(W[k][0], He);
+        row_sums(W[k][1], Ho);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             P[0][j] = P[1][j];
