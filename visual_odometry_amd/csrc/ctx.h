@@ -66,7 +66,7 @@ struct vo_ctx {
     DevBuf d_selcand; // Cand [frame][max_cand]: device selection, level l's picks (copies) at lvlofs[l]
     DevBuf d_selcnt;  // int [frame][VO_ORB_MAX_LEVELS]
     DevBuf d_flags;   // int [frame]: VO_SEL_* flags of the device selection
-    DevBuf d_sel;     // Cand [frame][kp_cap]: keypoints selected on the host (fallback path)
+    DevBuf d_sel;     // Cand [frame][kp_cap]: selected keypoints in keypoint order (k_sel_flatten; rows of flagged frames from the host selection)
     DevBuf d_coef;    // resize coefficient tables
     DevBuf d_geom;    // PyrGeom
     DevBuf d_kp;      // vo_keypoint [frame][kp_cap]

@@ -1051,6 +1051,51 @@ __global__ void k_sel_count(const PyrGeom* __restrict__ g, const int* __restrict
     nkp[f] = n;
 }
 
+// k_sel_count for the detection path that describes with k_orient_rbrief: besides the count, the frame's
+// per-level lists are copied into one list in keypoint order (flat[f][k], the layout of the host selection's
+// d_sel), so that the describing kernel finds its candidate by index alone instead of walking the level
+// counts first -- one dependent load less in front of its pixel loads.  One block per frame (+ one for the
+// sentinel count).
+__global__ __launch_bounds__(256) void k_sel_flatten(const PyrGeom* __restrict__ g, const int* __restrict__ selcnt,
+                                                     const int* __restrict__ lvlofs, const Cand* __restrict__ selcand,
+                                                     int max_cand, int* __restrict__ flags, int* __restrict__ nkp,
+                                                     int n_bound, int nframes, Cand* __restrict__ flat, int kp_cap) {
+    const int f = blockIdx.x;
+    if (f == nframes) {
+        if (threadIdx.x == 0) nkp[f] = 0;
+        return;
+    }
+    const int nl = g->nlevels;
+    int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS], n = 0;
+#pragma unroll
+    for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+        cnt[i] = i < nl ? selcnt[(size_t)f * VO_ORB_MAX_LEVELS + i] : 0;
+        ofs[i] = lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + i];
+        n += cnt[i];
+    }
+    if (n > n_bound) {
+        if (threadIdx.x == 0) atomicOr(&flags[f], VO_SEL_OVERFLOW);
+        n = n_bound;
+    }
+    if (threadIdx.x == 0) nkp[f] = n;
+    const uint4* src = reinterpret_cast<const uint4*>(selcand + (size_t)f * max_cand);
+    uint4* dst = reinterpret_cast<uint4*>(flat + (size_t)f * kp_cap);
+    static_assert(sizeof(Cand) == 16, "candidates are copied as 16-byte words");
+    for (int k = threadIdx.x; k < n; k += 256) {
+        int rem = k, at = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
+            if (!found && rem < cnt[i]) {
+                found = true;
+                at = ofs[i] + rem;
+            }
+            if (!found) rem -= cnt[i];
+        }
+        dst[k] = src[at];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // IC angle: integer moments over the radius-15 disc (umax rows), fastAtan2, then the keypoint
 // is written in level-0 coordinates (pt *= scale).  One wave per keypoint.
@@ -1491,61 +1536,28 @@ __global__ __launch_bounds__(256) void k_rbrief(const PyrGeom* __restrict__ g, c
 // of the keypoint record through memory between them happen once.  Same arithmetic, same results.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                       const PyrGeom* __restrict__ g, const Cand* __restrict__ sel,
-                                                       const int* __restrict__ flags, int max_cand,
-                                                       const Cand* __restrict__ selcand, const int* __restrict__ selcnt,
-                                                       const int* __restrict__ lvlofs, const int* __restrict__ nkp,
-                                                       int kp_cap, vo_keypoint* __restrict__ out,
-                                                       uint8_t* __restrict__ desc) {
+                                                       const PyrGeom* __restrict__ g, const Cand* __restrict__ flat,
+                                                       const int* __restrict__ nkp, int kp_cap,
+                                                       vo_keypoint* __restrict__ out, uint8_t* __restrict__ desc) {
     __shared__ __attribute__((aligned(16))) float patf[1024];
     __shared__ uint32_t win[RB_KP][RB_ROWS * RB_DW];
     __shared__ float s_m01[RB_KP], s_m10[RB_KP], s_ca[RB_KP], s_sa[RB_KP];
     const int tid = threadIdx.x;
     int bx, f;
     xcd_frame_block(bx, f);
-    const int n = nkp[f];
-    int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
-    {
-        const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
-        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
-#pragma unroll
-        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
-            cnt[i] = sc[i];
-            ofs[i] = lo[i];
-        }
-    }
     const int k0 = bx * RB_KP;
+    const int slot = tid >> 5, b = tid & 31;
+    // The count and the group's candidate (flat[f][k]: k_sel_flatten's list, or the host selection's rows of a
+    // flagged frame) are requested together; a slot at or beyond the count holds no candidate (stale memory):
+    // it is replaced before anything is derived from it and loads no pixels.
+    const int n = nkp[f];
+    Cand cd = flat[(size_t)f * kp_cap + min(k0 + slot, kp_cap - 1)];
     if (k0 >= n) return;  // the whole block
-    const int slot = tid >> 5, b = tid & 31, k = min(k0 + slot, n - 1);
+    const int k = min(k0 + slot, n - 1);
     const bool live = k0 + slot < n;
     const uint32_t q = reinterpret_cast<const uint32_t*>(c_orb_pattern)[tid];
-    Cand cd;
-    int lg;
-    // sel != NULL: the frames flagged in `flags` take their keypoints from the host selection
-    if (sel && flags[f] != 0) {
-        cd = sel[(size_t)f * kp_cap + k];
-        lg = cd.level;
-    } else {
-        const int nl = g->nlevels;
-        int l = 0, rem = k, base = 0;
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
-            if (i >= nl) break;  // uniform: half the table is unused at eight levels
-            if (!found) {
-                if (rem < cnt[i]) {
-                    found = true;
-                    l = i;
-                    base = ofs[i];
-                } else {
-                    rem -= cnt[i];
-                }
-            }
-        }
-        if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
-        lg = l;
-        cd = selcand[(size_t)f * max_cand + base + rem];
-    }
+    if (!live) cd.x = cd.y = cd.level = 0;
+    const int lg = cd.level;
     {
         float4 v;
         v.x = (float)(int8_t)(q & 0xff);
@@ -1557,9 +1569,17 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
         // slot started 128 bytes after its neighbour's: all in the same four banks, a 32-way conflict per read)
         reinterpret_cast<float4*>(patf)[(tid & 7) * 32 + (tid >> 3)] = v;
     }
-    const int pitch = g->lv[lg].pitch, h = g->lv[lg].h;
-    const unsigned lofs = g->lv[lg].offset;
-    const float lscale = g->lv[lg].scale;
+    // a block's keypoints are neighbours in level order: nearly always one level per wave, whose geometry then
+    // comes by scalar loads (a short hop) instead of a second round of vector loads
+    int pitch, h;
+    unsigned lofs;
+    float lscale;
+    const int lg0 = __builtin_amdgcn_readfirstlane(lg);
+    if (__builtin_amdgcn_ballot_w64(lg != lg0) == 0) {
+        pitch = g->lv[lg0].pitch, h = g->lv[lg0].h, lofs = g->lv[lg0].offset, lscale = g->lv[lg0].scale;
+    } else {
+        pitch = g->lv[lg].pitch, h = g->lv[lg].h, lofs = g->lv[lg].offset, lscale = g->lv[lg].scale;
+    }
     const size_t fofs = (size_t)f * g->pyr_bytes;
     // --- orientation: the lane's patch row
     const int r = min(b, 30), v = r - 15;
@@ -1568,8 +1588,10 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
     {
         const int xw = (cd.x - 15) & ~3;
         oi = (cd.x - 15) - xw;
-        const uint32_t* row = reinterpret_cast<const uint32_t*>(pyr + fofs + lofs +
-                                                                (size_t)__mul24(VO_PADY + cd.y + v, pitch) + VO_PADX + xw);
+        // a slot without a candidate reads the first bytes of the frame's pyramid instead of a patch: no branch
+        // around the loads (one per load would make each wait for the one before)
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(
+            pyr + fofs + (live ? lofs + (size_t)__mul24(VO_PADY + cd.y + v, pitch) + VO_PADX + xw : (size_t)0));
         const uint32_t* msk = c_ic_masks.m[v < 0 ? -v : v][oi];
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -1748,14 +1770,18 @@ void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, co
 
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
                        const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
-                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes) {
+                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes, Cand* flat, int kp_cap) {
     const size_t lds = (size_t)sel_cap * (sizeof(RI) + 2 * sizeof(uint16_t));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_select),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_orb_select, dim3(nframes, hg.nlevels), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
                        max_cand, quota, sel_cap, selcand, selcnt, flags);
-    hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
-                       n_bound, nframes);
+    if (flat)
+        hipLaunchKernelGGL(k_sel_flatten, dim3(nframes + 1), dim3(256), 0, st, d_geom, selcnt, lvlofs, selcand,
+                           max_cand, flags, nkp, n_bound, nframes, flat, kp_cap);
+    else
+        hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
+                           n_bound, nframes);
 }
 
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
@@ -1789,11 +1815,9 @@ void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, c
 }
 
 void launch_orient_rbrief(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, const PyrGeom* d_geom,
-                          const Cand* sel, const int* flags, int max_cand, const Cand* selcand, const int* selcnt,
-                          const int* lvlofs, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
+                          const Cand* flat, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
                           int nframes) {
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, RB_KP), nframes);
-    hipLaunchKernelGGL(k_orient_rbrief, grid, dim3(256), 0, st, pyr, blur, d_geom, sel, flags, max_cand, selcand,
-                       selcnt, lvlofs, nkp, kp_cap, out, desc);
+    hipLaunchKernelGGL(k_orient_rbrief, grid, dim3(256), 0, st, pyr, blur, d_geom, flat, nkp, kp_cap, out, desc);
 }

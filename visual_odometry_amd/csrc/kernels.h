@@ -111,8 +111,7 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
 void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* pyr, int level,
                        const uint32_t* xtab, const uint32_t* ytab, int ldw, int lrows, int nframes);
 void launch_orient_rbrief(hipStream_t st, const uint8_t* pyr, const uint8_t* blur, const PyrGeom* d_geom,
-                          const Cand* sel, const int* flags, int max_cand, const Cand* selcand, const int* selcnt,
-                          const int* lvlofs, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
+                          const Cand* flat, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
                           int nframes);
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
                      unsigned long long* masks, int threshold, int border, int nms, int nframes);
@@ -124,7 +123,7 @@ void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, co
                    int max_cand, int grid_cand, const int* only_flagged, int nframes);
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
                        const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
-                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes);
+                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes, Cand* flat, int kp_cap);
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
                      int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes);

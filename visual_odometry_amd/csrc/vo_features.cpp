@@ -323,7 +323,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     // d_flags was zeroed by the row scan of this batch (feat_detect)
     launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom, c->d_lvlofs.as<int>(),
                       c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
-                      c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes);
+                      c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes, c->d_sel.as<Cand>(), c->kp_cap);
     return vo_check_launch(c, "keypoint selection");
 }
 
@@ -411,9 +411,9 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     const char* split_env = getenv("VO_ORB_SPLIT");  // 1: orientation and description as two kernels (read per call)
     const bool split = split_env && atoi(split_env) != 0;
     if (angles && !split) {
-        launch_orient_rbrief(c->stream, c->d_pyr.as<uint8_t>(), c->d_blur.as<uint8_t>(), dg,
-                             host_selection ? c->d_sel.as<Cand>() : nullptr, c->d_flags.as<int>(), c->max_cand,
-                             c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(), c->d_lvlofs.as<int>(),
+        // d_sel: the device selection's lists flattened by k_sel_flatten, with the rows of flagged frames
+        // replaced by the host selection in the redo
+        launch_orient_rbrief(c->stream, c->d_pyr.as<uint8_t>(), c->d_blur.as<uint8_t>(), dg, c->d_sel.as<Cand>(),
                              c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
                              c->d_desc.as<uint8_t>(), nframes);
         return vo_check_launch(c, "feature description");
