@@ -36,6 +36,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Four chunks in flight need a hardware queue each; HIP gives a process four by default (GPU_MAX_HW_QUEUES), one
+# of which carries the default stream, so with the default the fourth compute stream shares a queue and the
+# step is 18 % slower than with three streams, with eight it is 5 % faster (sweep in DESIGN.md, section 6).
+# The HIP runtime reads the variable when it initialises, so it is set here, before anything touches the GPU
+# (child ranks inherit it).  --hw-queues 0 leaves the environment as it is.
+def _hw_queues_from_argv(default=8):
+    for i, a in enumerate(sys.argv):
+        if a == "--hw-queues" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith("--hw-queues="):
+            return int(a.split("=", 1)[1])
+    return default
+
+
+_HWQ = _hw_queues_from_argv()
+if _HWQ > 0:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(min(_HWQ, 32))
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # Matcher on the matrix cores: one v_mfma_i32_32x32x32_i8 (32 train rows x 32 queries x 32 bit positions =
@@ -222,7 +240,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=3, help="chunks in flight (HIP streams)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="chunks in flight (HIP streams); 0 = 4 when the process has more than four hardware queues, else 3")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="GPU_MAX_HW_QUEUES for this process (read at the top of the file, before HIP starts); 0: leave it")
     ap.add_argument("--chunk", type=int, default=48, help="frame pairs per chunk")
     ap.add_argument("--frames", type=int, default=4541, help="frames of the N = 1 sequence (seq 00: 4541)")
     ap.add_argument("--base-frames", type=int, default=289, help="rendered frames the long sequences are cut from")
@@ -237,6 +258,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: launch, sharding, barriers and the trajectory gather only (CPU plumbing test)")
     args = ap.parse_args()
+    if args.streams <= 0:
+        args.streams = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4 else 3
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -542,6 +565,7 @@ def main():
             "config": {"workload": workload, "sequences": len(lengths), "frames_per_step": sum(lengths),
                        "pairs_per_step": total_pairs_per_step, "nfeatures": args.nfeatures,
                        "ransac_max_iters": args.max_iters, "streams": args.streams, "pairs_per_chunk": args.chunk,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "rendered_base_frames": base_n,
                        "parallelism": "sequence shards x%d (LPT by frame count), no data-path collective" % world},
             "timed_region_s": elapsed,
