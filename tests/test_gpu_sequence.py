@@ -70,13 +70,13 @@ def test_seq_host_pageable_and_strided(seq_frames, batch_results):
 
 @pytest.mark.parametrize("prefetch", [True, False])
 def test_seq_host_pinned(seq_frames, batch_results, prefetch, monkeypatch):
-    """Frames in pinned host memory: uploaded ahead of time on a copy stream (default) or, with
-    VO_SEQ_PREFETCH=0, on the chunk's own stream; the same results either way."""
+    """Frames in pinned host memory: uploaded on the chunk's own stream (default) or, with VO_SEQ_PREFETCH=1,
+    ahead of time on a copy stream; the same results either way."""
     fr, _ = seq_frames
     n = fr.shape[0]
     pinned = torch.from_numpy(fr).pin_memory()
-    if not prefetch:
-        monkeypatch.setenv("VO_SEQ_PREFETCH", "0")
+    if prefetch:
+        monkeypatch.setenv("VO_SEQ_PREFETCH", "1")
     seq = api.VoSequence(0, n_streams=2, pairs_per_chunk=5)
     res = seq.run(pinned.data_ptr(), n, W, H, W, W * H, KS, api.pair_params(500), mem=api.MEM_HOST_PINNED)
     assert [as_tuple(r) for r in res] == batch_results

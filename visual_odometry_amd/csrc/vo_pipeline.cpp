@@ -341,11 +341,13 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
             rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm, details));
             continue;
         }
-        // VO_SEQ_PREFETCH=0: no copy stream, the chunk's frames go up on its own stream in front of its kernels
-        // (the copies of the other chunks still overlap them); read per run
+        // Pinned frames go up on the chunk's own stream in front of its kernels: the copies of the other chunks
+        // overlap them, and no further streams compete for the process's hardware queues (108 k pairs/s against
+        // 87 k with four chunks in flight).  VO_SEQ_PREFETCH=1: the earlier scheme, every context sends chunk
+        // k + S ahead of time on a copy stream of its own into a second image buffer; read per run.
         static const char* pf_env = nullptr;
         if (k == 0) pf_env = getenv("VO_SEQ_PREFETCH");
-        const bool prefetch = !(pf_env && atoi(pf_env) == 0);
+        const bool prefetch = pf_env && atoi(pf_env) != 0;
         if (mem == VO_MEM_HOST_PINNED && stride == w && frame_stride == img && prefetch) {
             vo_seq::Prefetch& P = s->pre[slot];
             const size_t need = (size_t)(B + 1) * img;
