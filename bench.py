@@ -560,7 +560,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "u8 features/descriptors, u32 popcount matching, f64 geometry",
+            "dtype": "u8 features/descriptors, i8 x i8 -> i32 matrix-core Hamming matching (exact), f64 geometry",
             "data": "synthetic (seeded planar-world KITTI-shaped frames rendered by visual_odometry_amd/synth.py)",
             "config": {"workload": workload, "sequences": len(lengths), "frames_per_step": sum(lengths),
                        "pairs_per_step": total_pairs_per_step, "nfeatures": args.nfeatures,
