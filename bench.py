@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0,
                     help="chunks in flight (HIP streams); 0 = 4 when the process has more than four hardware queues, else 3")
+    ap.add_argument("--no-default-queues", action="store_true",
+                    help="skip the child run that repeats the step with HIP's default number of hardware queues")
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (read at the top of the file, before HIP starts); 0: leave it")
     ap.add_argument("--chunk", type=int, default=48, help="frame pairs per chunk")
@@ -258,6 +260,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: launch, sharding, barriers and the trajectory gather only (CPU plumbing test)")
     args = ap.parse_args()
+    explicit_streams = args.streams > 0
     if args.streams <= 0:
         args.streams = 4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > 4 else 3
 
@@ -273,6 +276,38 @@ def main():
         sys.exit(2)
 
     from visual_odometry_amd import shard, synth
+
+    # ---- the same step in a child process that keeps HIP's default of four hardware queues (three chunks in
+    # flight): what a host application gets if it does not raise GPU_MAX_HW_QUEUES before its first HIP call.
+    # Run first, while this process has not touched the GPU; the rendered frames are shared through a cache.
+    default_queues = None
+    # (only for the default configuration: a run with --streams given, as the profiling scripts do, is not it)
+    if (world == 1 and _HWQ > 0 and not args.no_default_queues and not args.dry_run and args.workload == "auto"
+            and not explicit_streams):
+        import atexit
+        import shutil
+        import tempfile
+
+        tmp_cache = None
+        if not os.environ.get("VO_SYNTH_CACHE"):
+            tmp_cache = tempfile.mkdtemp(prefix="vo_synth_")
+            os.environ["VO_SYNTH_CACHE"] = tmp_cache
+            atexit.register(shutil.rmtree, tmp_cache, True)
+        try:
+            env = dict(os.environ)
+            env.pop("GPU_MAX_HW_QUEUES", None)
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--hw-queues", "0", "--steps", "8",
+                                  "--warmup", "2", "--frames", str(args.frames), "--base-frames",
+                                  str(args.base_frames), "--chunk", str(args.chunk), "--nfeatures",
+                                  str(args.nfeatures), "--max-iters", str(args.max_iters), "--no-cpu-baseline",
+                                  "--no-8k", "--no-pcie", "--no-default-queues"],
+                                 env=env, capture_output=True, text=True, timeout=300)
+            child = json.loads(out.stdout.strip().splitlines()[-1])
+            default_queues = {"value": child["value"], "unit": "frame-pairs/s",
+                              "streams": child["config"]["streams"], "hw_queues": child["config"]["hw_queues"],
+                              "note": "same step in a child process with GPU_MAX_HW_QUEUES unset (HIP's default: 4)"}
+        except Exception as e:  # a side measurement: never fails the line
+            default_queues = {"value": None, "note": "child run failed: %r" % (e,)}
 
     # ---- which sequences this rank runs ---------------------------------------------------------------
     multi = world > 1 or args.workload == "configs4"
@@ -573,6 +608,7 @@ def main():
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
             "side": side,
+            "default_queues": default_queues,
             "detector_roofline": detector,
             "pcie_inclusive": pcie,
             "lpt_imbalance": imbalance,

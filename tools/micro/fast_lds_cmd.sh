@@ -1,7 +1,7 @@
 # SQ counters of k_fast_nms on the 49-frame batch (run through gpurun): LDS side and wait side, one pass each
 set -e
 export TMPDIR=/tmp VO_SYNTH_CACHE=/tmp/vo_synth_cache
-ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie"
+ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie --no-default-queues"
 OUT=gpurun_out/${1:-fast_lds}
 mkdir -p $OUT
 timeout -k 10 240 python3 bench.py $ARGS --steps 1 --warmup 0 > /dev/null 2>&1

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp VO_SYNTH_CACHE=/tmp/vo_synth_cache VO_SYNTH_NOFORK=0
 timeout -k 10 400 python3 -u -m pytest tests/test_gpu_features.py tests/test_gpu_real_images.py -x -q -m gpu --timeout 120 --timeout-method thread > $OUT/tests.log 2>&1 || { tail -30 $OUT/tests.log; exit 1; }
 tail -2 $OUT/tests.log
-ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie"
+ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie --no-default-queues"
 timeout -k 10 240 python3 bench.py $ARGS --steps 1 --warmup 0 > $OUT/render.log 2>&1
 export VO_SYNTH_NOFORK=1
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py $ARGS --steps 10 --warmup 1 > $OUT/trace.log 2>&1
