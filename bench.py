@@ -301,7 +301,7 @@ def main():
                                   str(args.base_frames), "--chunk", str(args.chunk), "--nfeatures",
                                   str(args.nfeatures), "--max-iters", str(args.max_iters), "--no-cpu-baseline",
                                   "--no-8k", "--no-pcie", "--no-default-queues"],
-                                 env=env, capture_output=True, text=True, timeout=300)
+                                 env=env, capture_output=True, text=True, timeout=150)
             child = json.loads(out.stdout.strip().splitlines()[-1])
             default_queues = {"value": child["value"], "unit": "frame-pairs/s",
                               "streams": child["config"]["streams"], "hw_queues": child["config"]["hw_queues"],
