@@ -81,7 +81,7 @@ struct vo_ctx {
     // (synchronise + copy out) hands them to the caller.  The arena is recycled at every finish.
     DevBuf d_pack;       // result tables of a batch gathered for one device -> host copy
     PinnedBuf h_pack;
-    size_t pack_at[5] = {0, 0, 0, 0, 0}, pack_bytes[5] = {0, 0, 0, 0, 0};
+    size_t pack_at[8] = {}, pack_bytes[8] = {};  // byte offset and size of table i in d_pack / h_pack
     double cam_cache[4] = {0, 0, 0, 0};  // camera table on the device: K it was built from, pairs it covers
     int cam_pairs = 0;
     const void* cam_ptr = nullptr;
@@ -169,7 +169,6 @@ struct vo_ctx {
     int pipe_frames = 0, pipe_ncap = 0;
     int pend_frames = 0;  // frames of the batch queued by pairs_submit and not yet collected
     bool pend_details = false;  // that batch also brings its match / mask tables to the host
-    PinnedBuf h_dgood, h_dmask;  // GoodMatch [pair][n_cap]; uint8 [2][pair][n_cap] (inlier mask, pose mask)
     double pend_K[9];
     vo_pair_params pend_prm;
     std::vector<int> pipe_nkp;

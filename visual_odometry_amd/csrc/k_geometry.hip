@@ -692,7 +692,7 @@ void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps
 __global__ __launch_bounds__(256) void k_pack_results(PackArgs a, uint32_t* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
+    for (int t = 0; t < VO_PACK_TABLES; t++) {
         const int j = i - a.at[t];
         if (j >= 0 && j < a.ndw[t]) out[i] = a.src[t][j];
     }

@@ -70,10 +70,11 @@ struct Taps7 {
     int t[7];
 };
 // blocks of the blur launch: level l owns blocks [b0[l], b0[l+1]), bx[l] of them per block row
-struct PackArgs {  // five dword tables gathered into one buffer, table i at dword at[i]
-    const uint32_t* src[5];
-    int ndw[5];
-    int at[5];
+#define VO_PACK_TABLES 8
+struct PackArgs {  // up to eight dword tables gathered into one buffer, table i at dword at[i] (unused: ndw 0)
+    const uint32_t* src[VO_PACK_TABLES];
+    int ndw[VO_PACK_TABLES];
+    int at[VO_PACK_TABLES];
 };
 void launch_pack_results(hipStream_t st, const PackArgs& a, int total_dw, uint32_t* out);
 

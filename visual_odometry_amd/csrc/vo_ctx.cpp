@@ -195,7 +195,7 @@ void vo_ctx_destroy(vo_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     PinnedBuf* pin[] = {&c->h_lvlofs, &c->h_cand, &c->h_sel,  &c->h_nkp,  &c->h_misc, &c->h_flags, &c->h_knn,
                         &c->h_good,   &c->h_state, &c->h_pose, &c->h_mask, &c->h_pts, &c->h_img,
-                        &c->h_xfer, &c->h_pack, &c->h_dgood, &c->h_dmask, &c->h_ak};
+                        &c->h_xfer, &c->h_pack, &c->h_ak};
     for (PinnedBuf* b : pin)
         if (b->p) (void)hipHostFree(b->p);
     for (int i = 0; i < VO_PROF_COUNT; i++) {

@@ -40,17 +40,22 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
     VO_TRY(vo_ensure_pinned(c, c->h_state, (size_t)npairs * sizeof(EstState)));
     VO_TRY(vo_ensure_pinned(c, c->h_pose, (size_t)npairs * sizeof(PoseState)));
     VO_TRY(vo_ensure_pinned(c, c->h_good, (size_t)npairs * sizeof(int)));
-    // One copy instead of five: the result tables (estimator and pose states, match counts, keypoint
-    // counts, selection flags) are gathered into one device buffer and cross the bus together.
+    // One copy instead of five (eight with the detail tables): the result tables (estimator and pose states,
+    // match counts, keypoint counts, selection flags) and, for vo_seq_run_ex, the per-pair tables the
+    // reference's matcher() / updatePose() hand back (MatchesInfo::matches, inliers_mask, recoverPose's mask;
+    // fixed stride n_cap, pairs_collect copies the used rows out) are gathered into one device buffer and
+    // cross the bus together: every separate copy is a launch of its own at the end of the chunk's stream.
     PackArgs pa;
-    const void* src[5] = {c->d_state.p, c->d_pose.p, c->d_ngood.p, c->d_nkp.p, c->d_flags.p};
-    const size_t bytes[5] = {(size_t)npairs * sizeof(EstState), (size_t)npairs * sizeof(PoseState),
-                             (size_t)npairs * sizeof(int), (size_t)n_frames * sizeof(int),
-                             (size_t)n_frames * sizeof(int)};
+    const size_t rows = c->pend_details ? (size_t)npairs * n_cap : 0;
+    const void* src[VO_PACK_TABLES] = {c->d_state.p, c->d_pose.p, c->d_ngood.p, c->d_nkp.p,
+                                       c->d_flags.p, c->d_good.p, c->d_mask.p, c->d_pmask.p};
+    const size_t bytes[VO_PACK_TABLES] = {(size_t)npairs * sizeof(EstState), (size_t)npairs * sizeof(PoseState),
+                                          (size_t)npairs * sizeof(int), (size_t)n_frames * sizeof(int),
+                                          (size_t)n_frames * sizeof(int), rows * sizeof(GoodMatch), rows, rows};
     int at = 0;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < VO_PACK_TABLES; i++) {
         pa.src[i] = static_cast<const uint32_t*>(src[i]);
-        pa.ndw[i] = (int)(bytes[i] / 4);
+        pa.ndw[i] = (int)((bytes[i] + 3) / 4);  // a last partial dword lies inside the allocation (256-byte units)
         pa.at[i] = at;
         c->pack_at[i] = (size_t)at * 4;
         c->pack_bytes[i] = bytes[i];
@@ -61,16 +66,6 @@ static int pairs_after_selection(vo_ctx* c, int n_frames, int max_n, const doubl
     launch_pack_results(c->stream, pa, at, c->d_pack.as<uint32_t>());
     VO_TRY(vo_check_launch(c, "result gather"));
     VO_HIP(c, hipMemcpyAsync(c->h_pack.p, c->d_pack.p, (size_t)at * 4, hipMemcpyDeviceToHost, c->stream));
-    if (c->pend_details) {
-        // the per-pair tables the reference's matcher() / updatePose() hand back (MatchesInfo::matches,
-        // inliers_mask, recoverPose's mask), fixed stride n_cap; pairs_collect copies the used rows out
-        const size_t rows = (size_t)npairs * n_cap;
-        VO_TRY(vo_ensure_pinned(c, c->h_dgood, rows * sizeof(GoodMatch)));
-        VO_TRY(vo_ensure_pinned(c, c->h_dmask, 2 * rows));
-        VO_HIP(c, hipMemcpyAsync(c->h_dgood.p, c->d_good.p, rows * sizeof(GoodMatch), hipMemcpyDeviceToHost, c->stream));
-        VO_HIP(c, hipMemcpyAsync(c->h_dmask.p, c->d_mask.p, rows, hipMemcpyDeviceToHost, c->stream));
-        VO_HIP(c, hipMemcpyAsync(c->h_dmask.as<uint8_t>() + rows, c->d_pmask.p, rows, hipMemcpyDeviceToHost, c->stream));
-    }
     c->pipe_ncap = n_cap;
     return VO_OK;
 }
@@ -158,16 +153,21 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out,
     }
     c->pipe_frames = n_frames;
     if (out && c->pend_details) {
-        const size_t n_cap = (size_t)c->pipe_ncap, rows = (size_t)npairs * n_cap;
+        const size_t n_cap = (size_t)c->pipe_ncap;
         const size_t cap = (size_t)out->match_cap;
+        // the detail tables are read where they arrived, in the gathered buffer
+        const char* hp = c->h_pack.as<char>();
+        const GoodMatch* h_good = reinterpret_cast<const GoodMatch*>(hp + c->pack_at[5]);
+        const uint8_t* h_mask = reinterpret_cast<const uint8_t*>(hp + c->pack_at[6]);
+        const uint8_t* h_pmask = reinterpret_cast<const uint8_t*>(hp + c->pack_at[7]);
         for (int p = 0; p < npairs; p++) {
             const size_t cnt = (size_t)ng[p];
             if (cnt > cap)
                 return c->fail(VO_ERR_CAPACITY, "pair %zu has %zu matches, match_cap is %zu", pair0 + p, cnt, cap);
             const size_t at = (pair0 + p) * cap;
-            if (out->matches) memcpy(out->matches + at, c->h_dgood.as<GoodMatch>() + p * n_cap, cnt * sizeof(GoodMatch));
-            if (out->inlier_mask) memcpy(out->inlier_mask + at, c->h_dmask.as<uint8_t>() + p * n_cap, cnt);
-            if (out->pose_mask) memcpy(out->pose_mask + at, c->h_dmask.as<uint8_t>() + rows + p * n_cap, cnt);
+            if (out->matches) memcpy(out->matches + at, h_good + p * n_cap, cnt * sizeof(GoodMatch));
+            if (out->inlier_mask) memcpy(out->inlier_mask + at, h_mask + p * n_cap, cnt);
+            if (out->pose_mask) memcpy(out->pose_mask + at, h_pmask + p * n_cap, cnt);
         }
     }
     return VO_OK;
