@@ -85,15 +85,15 @@ def test_akaze_parameters_and_odd_sizes(vo, oracle):
         vo.akaze_detect_compute(im, api.akaze_params(pattern_size=7))
 
 
-def test_akaze_graph_replay_equals_plain_launches(vo, monkeypatch):
-    """Phase 1 runs as a captured hipGraph by default; VO_AKAZE_GRAPH=0 queues the same kernels one by one.
+def test_akaze_graph_replay_equals_plain_launches(vo):
+    """Phase 1 runs as a captured hipGraph by default; VO_OPT_AKAZE_GRAPH = 0 queues the same kernels one by one.
     Same keypoints and descriptors, also when the graph is re-captured for another size and replayed again."""
     a, b = load("000000"), np.ascontiguousarray(load("000003")[:300, :900])
     ref = {}
-    monkeypatch.setenv("VO_AKAZE_GRAPH", "0")
+    vo.set_option(api.OPT_AKAZE_GRAPH, 0)
     for name, im in (("a", a), ("b", b)):
         ref[name] = vo.akaze_detect_compute(im)
-    monkeypatch.setenv("VO_AKAZE_GRAPH", "1")
+    vo.set_option(api.OPT_AKAZE_GRAPH, 1)
     for name, im in (("a", a), ("b", b), ("a", a), ("a", a)):
         k, d = vo.akaze_detect_compute(im)
         assert np.array_equal(k, ref[name][0]) and np.array_equal(d, ref[name][1]), name

@@ -312,17 +312,19 @@ def test_orb_edge_threshold_below_the_window_radius_is_refused(vo, frames):
 
 
 @pytest.mark.parametrize("edge", [31, 19])
-def test_orb_fused_orientation_description_equals_the_two_kernels(vo, oracle, frames, edge, monkeypatch):
+def test_orb_fused_orientation_description_equals_the_two_kernels(vo, oracle, frames, edge):
     """The detection path computes the IC angle and the rBRIEF descriptor in one kernel (k_orient_rbrief);
-    VO_ORB_SPLIT=1 runs k_ic_angle and k_rbrief apart.  Same keypoints (angle included), same descriptors, both
+    VO_OPT_ORB_SPLIT = 1 runs k_ic_angle and k_rbrief apart.  Same keypoints (angle included), same descriptors, both
     equal to the oracle, at the default border and at the smallest one accepted."""
     from visual_odometry_amd import api
 
     img = frames[0][1]
     pg = api.orb_params(2000, edge_threshold=edge)
-    monkeypatch.setenv("VO_ORB_SPLIT", "1")
-    ks, ds = vo.orb_detect_compute(img, pg)
-    monkeypatch.delenv("VO_ORB_SPLIT")
+    vo.set_option(api.OPT_ORB_SPLIT, 1)
+    try:
+        ks, ds = vo.orb_detect_compute(img, pg)
+    finally:
+        vo.set_option(api.OPT_ORB_SPLIT, 0)
     kf, df = vo.orb_detect_compute(img, pg)
     assert len(kf) > 1500
     assert np.array_equal(kf, ks) and np.array_equal(df, ds)

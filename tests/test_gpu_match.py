@@ -4,7 +4,7 @@ Reads like the reference's use in matcher() (src/matcher/matcher.cpp:17-38)."""
 import numpy as np
 import pytest
 
-from visual_odometry_amd import synth
+from visual_odometry_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -176,9 +176,9 @@ def test_cross_check_option(vo, oracle, nq, nt):
 
 
 @pytest.mark.parametrize("nq,nt", [(1, 1), (31, 33), (64, 64), (65, 129), (500, 257), (2000, 1987), (3000, 4100)])
-def test_knn2_matrix_core_kernel_equals_popcount_kernel(vo, oracle, nq, nt, monkeypatch):
+def test_knn2_matrix_core_kernel_equals_popcount_kernel(vo, oracle, nq, nt):
     """32-byte rows: k_knn2_mfma (int8 dot products on the matrix cores, the default) and k_knn2<8> (xor +
-    popcount, VO_KNN_MFMA=0) are two independent formulations of the same integers; both must give the oracle's
+    popcount, VO_OPT_KNN_MFMA = 0) are two independent formulations of the same integers; both must give the oracle's
     table, ties included (rows drawn from 8 distinct values make most distances tie)."""
     rng = np.random.default_rng(nq * 7919 + nt)
     for kind in ("random", "ties"):
@@ -189,9 +189,11 @@ def test_knn2_matrix_core_kernel_equals_popcount_kernel(vo, oracle, nq, nt, monk
             pool = rng.integers(0, 256, (8, 32), dtype=np.uint8)
             q = pool[rng.integers(0, 8, nq)]
             t = pool[rng.integers(0, 8, nt)]
-        monkeypatch.setenv("VO_KNN_MFMA", "0")
-        gp, vp = vo.knn2_hamming(q, t)
-        monkeypatch.delenv("VO_KNN_MFMA")
+        vo.set_option(api.OPT_KNN_MFMA, 0)
+        try:
+            gp, vp = vo.knn2_hamming(q, t)
+        finally:
+            vo.set_option(api.OPT_KNN_MFMA, 1)
         gm, vm = vo.knn2_hamming(q, t)
         o, ov = oracle.knn2_hamming(q, t)
         assert np.array_equal(vp, vm) and np.array_equal(vm, ov)

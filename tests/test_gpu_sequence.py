@@ -69,15 +69,14 @@ def test_seq_host_pageable_and_strided(seq_frames, batch_results):
 
 
 @pytest.mark.parametrize("prefetch", [True, False])
-def test_seq_host_pinned(seq_frames, batch_results, prefetch, monkeypatch):
-    """Frames in pinned host memory: uploaded on the chunk's own stream (default) or, with VO_SEQ_PREFETCH=1,
+def test_seq_host_pinned(seq_frames, batch_results, prefetch):
+    """Frames in pinned host memory: uploaded on the chunk's own stream (default) or, with VO_OPT_SEQ_PREFETCH = 1,
     ahead of time on a copy stream; the same results either way."""
     fr, _ = seq_frames
     n = fr.shape[0]
     pinned = torch.from_numpy(fr).pin_memory()
-    if prefetch:
-        monkeypatch.setenv("VO_SEQ_PREFETCH", "1")
     seq = api.VoSequence(0, n_streams=2, pairs_per_chunk=5)
+    seq.ctx(0).set_option(api.OPT_SEQ_PREFETCH, int(prefetch))
     res = seq.run(pinned.data_ptr(), n, W, H, W, W * H, KS, api.pair_params(500), mem=api.MEM_HOST_PINNED)
     assert [as_tuple(r) for r in res] == batch_results
     seq.close()
@@ -239,3 +238,102 @@ def test_seq_run_multi_equals_separate_runs():
             for a, b in zip(o1, o2):
                 assert np.array_equal(a, b)
     seq.close()
+
+
+@pytest.mark.parametrize("ratio", [0.7, 0.97])
+def test_pair_results_do_not_depend_on_the_chunk_size(seq_frames, ratio):
+    """A pair's E, masks and pose must not depend on how many pairs share its launches (the
+    five-point solver used to be chosen from hypotheses x pairs of a launch, and the two solvers are not
+    bit-identical).  The same 48 pairs in one chunk of 48, in chunks of 5 and one pair at a time through
+    vo_pairs_run_dev: identical results, bit for bit.  ratio 0.97 lets many wrong matches through, so the
+    adaptive RANSAC runs its later, larger rounds (64 -> 256 -> 680 hypotheses) as well."""
+    fr, _ = seq_frames
+    n = 49
+    idx = synth.pingpong_indices(fr.shape[0], n)
+    d = torch.from_numpy(fr[idx]).to("cuda:0")
+    torch.cuda.synchronize()
+    prm = api.pair_params(500, ratio=ratio)
+    cap = 700
+    runs = []
+    for chunk in (48, 5):
+        seq = api.VoSequence(0, n_streams=2, pairs_per_chunk=chunk)
+        o = tuple(np.zeros((n - 1, cap), t) for t in (api.DM_DTYPE, np.uint8, np.uint8))
+        res = seq.run(d.data_ptr(), n, W, H, W, W * H, KS, prm, outputs=o)
+        runs.append(([as_tuple(r) for r in res], o))
+        seq.close()
+    (r48, o48), (r5, o5) = runs
+    assert r48 == r5
+    for a, b in zip(o48, o5):
+        assert np.array_equal(a, b)
+    assert all(r[5] == 0 for r in r48)
+    ctx = api.VoContext(0)
+    for p in (0, 7, 30, 47):
+        one = ctx.pairs_run_dev(d.data_ptr() + p * W * H, 2, W, H, W, W * H, KS, prm)
+        assert as_tuple(one[0]) == r48[p]
+    ctx.close()
+
+
+def test_seq_multi_configs4_full_shape(oracle):
+    """BASELINE.json configs[4] at its stated shape on ONE GPU: the 22 KITTI sequence lengths
+    (shard.KITTI_LENGTHS: 43 552 frames of 1241 x 376, 43 530 pairs) through vo_seq_run_multi in chunks of 48
+    pairs on 3 streams.  Every sequence is a window of one shared ping-pong buffer (4 981 frames = the longest
+    sequence), sequence i starting 3 i frames in, so memory stays at one buffer and the windows' chunk
+    boundaries fall at different frames.  Checked: every pair has a pose; three sequences equal separate
+    vo_seq_run_ex calls bit for bit; pair p of every sequence equals pair offset + p of the full-length
+    sequence (results do not depend on which sequence or chunk a pair sits in); first / last pairs of
+    sequences and pairs next to a sequence boundary match the oracle (matches and masks bit-exact, E / R / t
+    within 1e-6)."""
+    from visual_odometry_amd import shard
+
+    lengths = list(shard.KITTI_LENGTHS)
+    assert len(lengths) == 22 and sum(lengths) == 43552
+    lmax, base = max(lengths), 97
+    fr, _, Kc = synth.make_sequence(11, base, workers=8)
+    idx = synth.pingpong_indices(base, lmax)
+    d = torch.from_numpy(fr).to("cuda:0").index_select(0, torch.from_numpy(idx).to("cuda:0"))
+    torch.cuda.synchronize()
+    w, h = 1241, 376
+    offs = [min(3 * i, lmax - n) for i, n in enumerate(lengths)]
+    cap = 2314
+    outs = [tuple(np.zeros((n - 1, cap), t) for t in (api.DM_DTYPE, np.uint8, np.uint8)) for n in lengths]
+    prm = api.pair_params(2000)
+    seq = api.VoSequence(0, n_streams=3, pairs_per_chunk=48)
+    res = seq.run_multi([(d.data_ptr() + o * w * h, n) for o, n in zip(offs, lengths)], w, h, w, w * h, Kc, prm,
+                        outputs=outs)
+    assert seq.stats()[0] == sum((n - 1 + 47) // 48 for n in lengths)
+    for r, n in zip(res, lengths):
+        assert all(r[p].status == 0 and r[p].n_kp0 >= 2000 and r[p].n_good > 100 and r[p].n_pose > 50
+                   for p in range(n - 1))
+    # three sequences on their own (a short one, one that ends in a one-pair chunk, the first)
+    for i in (4, 17, 0):
+        n = lengths[i]
+        o1 = tuple(np.zeros((n - 1, cap), t) for t in (api.DM_DTYPE, np.uint8, np.uint8))
+        r1 = seq.run(d.data_ptr() + offs[i] * w * h, n, w, h, w, w * h, Kc, prm, outputs=o1)
+        assert [as_tuple(r1[p]) for p in range(n - 1)] == [as_tuple(res[i][p]) for p in range(n - 1)]
+        for a, b in zip(o1, outs[i]):
+            assert np.array_equal(a, b)
+    seq.close()
+    # every sequence is a window of the longest one
+    full = lengths.index(lmax)
+    assert offs[full] == 0
+    for i, n in enumerate(lengths):
+        for p in list(range(0, n - 1, 97)) + [n - 2]:
+            a, b = res[i][p], res[full][offs[i] + p]
+            assert as_tuple(a) == as_tuple(b), (i, p)
+            k = a.n_good
+            for ta, tb in zip(outs[i], outs[full]):
+                assert np.array_equal(ta[p, :k], tb[offs[i] + p, :k])
+    # oracle: first and last pair of sequences, the pairs either side of a sequence boundary in the chunk stream
+    for i, p in ((0, 0), (0, lengths[0] - 2), (1, 0), (4, lengths[4] - 2), (5, 0), (21, lengths[21] - 2), (19, 2500)):
+        g0 = offs[i] + p
+        o = _oracle_pair(oracle, fr[idx[g0]], fr[idx[g0 + 1]], 2000, Kc)
+        r = res[i][p]
+        k = r.n_good
+        m, im, pm = outs[i]
+        assert (r.n_kp0, r.n_kp1, k, r.status) == (o["nk0"], o["nk1"], len(o["good"]), o["rc"])
+        assert np.array_equal(m[p, :k], o["good"])
+        assert np.array_equal(im[p, :k], o["mask"]) and r.n_inliers == int(o["mask"].sum())
+        assert np.array_equal(pm[p, :k], o["pm"]) and r.n_pose == o["ng"]
+        Eg = np.array(r.E).reshape(3, 3)
+        assert min(np.abs(Eg - o["E"]).max(), np.abs(Eg + o["E"]).max()) < 1e-6
+        assert np.abs(np.array(r.R).reshape(3, 3) - o["R"]).max() < 1e-6 and np.abs(np.array(r.t) - o["t"]).max() < 1e-6

@@ -98,6 +98,14 @@ struct vo_ctx {
     int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
     int kp_cap = 0;
     int feat_frames = 0;
+    // Switches between equivalent kernel schedules (vo_ctx_set_option; the environment variables of the same
+    // names, VO_KNN_MFMA ..., are read ONCE, when the context is created)
+    int opt_knn_mfma = 1;      // 32-byte rows on the matrix-core matcher (0: popcount kernel)
+    int opt_orb_split = 0;     // 1: orientation and description as two kernels
+    int opt_seq_prefetch = 0;  // 1: pinned frames prefetched on a copy stream of the context's own
+    int opt_akaze_graph = 1;   // AKAZE scale space replayed from a captured hipGraph (0: plain launches)
+    int opt_solver = 0;        // five-point solver of findEssentialMat: 0 one hypothesis per 16-lane group, 1 per lane
+    int opt_knn_splits = 0;    // > 0: train-range splits of a single 2-NN problem (tuning hook)
 
     PyrGeom geom;  // host copy of d_geom
     int quota[VO_ORB_MAX_LEVELS];

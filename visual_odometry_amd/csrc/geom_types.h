@@ -41,7 +41,7 @@ void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const 
 void launch_five_point_batch(hipStream_t st, int count, bool coop, const double* x1, const double* x2, double* models,
                              int* nmodels);
 void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
-                   const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H, int npairs);
+                   const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H, int npairs, int per_lane);
 void launch_score(hipStream_t st, int h0, int h1, const EstState* s, const double2* x1, const double2* x2, int n_cap,
                   const double* models, const int* nmodels, int* counts, int H, int npairs);
 void launch_replay(hipStream_t st, int h0, int h1, EstState* s, const int* nmodels, const int* counts, int H,

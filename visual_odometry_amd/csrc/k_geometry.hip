@@ -21,7 +21,6 @@
 #include "five_point.h"
 #include "five_point_coop.h"
 
-#define VO_SOLVE_COOP_MAX 16384  // hypotheses per launch up to which the cooperative solver is used
 
 namespace {
 
@@ -612,18 +611,21 @@ void launch_normalize(hipStream_t st, const float2* p0, const float2* p1, const 
 
 void launch_solve5(hipStream_t st, int h0, int h1, const EstState* s, const uint16_t* samples, int samples_iters,
                    const double2* x1, const double2* x2, int n_cap, double* models, int* nmodels, int H,
-                   int npairs) {
-    // cooperative solver while the launch leaves SIMDs idle with one hypothesis per lane
-    static const int env_coop = getenv("VO_SOLVE_COOP") ? atoi(getenv("VO_SOLVE_COOP")) : -1;
-    const long total = (long)(h1 - h0) * npairs;
-    if (env_coop >= 0 ? env_coop != 0 : total <= VO_SOLVE_COOP_MAX) {
+                   int npairs, int per_lane) {
+    // Which solver runs is a property of the context (VO_OPT_SOLVER), never of the launch size: the two are
+    // not bit-identical (tests/test_gpu_geometry.py::test_five_point_lane_and_group_solvers_agree), so a rule
+    // that looked at (h1 - h0) * npairs would make a pair's E depend on how many pairs share its chunk.  The
+    // group solver is the default at every size: 48 pairs x 680 hypotheses take 52 us with it against 193 us
+    // one per lane (profiles/r3a_solver.txt), because a lane's 10 x 20 system needs 1.6 KB of LDS and one
+    // wave fills a CU.
+    if (!per_lane) {
         hipLaunchKernelGGL(k_solve5_coop, dim3(cdiv(h1 - h0, 4), npairs), dim3(64), 0, st, h0, h1, s, samples,
                            samples_iters, x1, x2, n_cap, models, nmodels, H);
         return;
     }
     int lanes = 64;
     while (lanes > 4 && (long)(h1 - h0) * npairs / lanes < 1024) lanes /= 2;
-    static const int env_lanes = getenv("VO_SOLVE_LANES") ? atoi(getenv("VO_SOLVE_LANES")) : 0;
+    static const int env_lanes = getenv("VO_SOLVE_LANES") ? atoi(getenv("VO_SOLVE_LANES")) : 0;  // tools/prof_solve.py
     if (env_lanes) lanes = env_lanes;
 #define VO_SOLVE5(L)                                                                                           \
     hipLaunchKernelGGL(k_solve5<L>, dim3(cdiv(h1 - h0, L), npairs), dim3(L), 0, st, h0, h1, s, samples, samples_iters, \

@@ -517,11 +517,9 @@ void launch_knn2(hipStream_t st, const KnnArgs& a) {
     if (nmax <= 0 || a.npairs <= 0) return;
     const int dirs = a.cross ? 2 : 1;
     dim3 grid(cdiv(nmax, 64), a.splits, a.npairs * dirs);
-    // 32-byte rows go to the matrix-core kernel; VO_KNN_MFMA=0 (read per call: the tests switch it) keeps them
-    // on the popcount kernel, which 64-byte rows always use
-    const char* env = getenv("VO_KNN_MFMA");
-    const bool mfma = !(env && atoi(env) == 0);
-    if (a.words == 8 && mfma) hipLaunchKernelGGL(k_knn2_mfma, grid, dim3(256), 0, st, a);
+    // 32-byte rows go to the matrix-core kernel; VO_OPT_KNN_MFMA = 0 keeps them on the popcount kernel, which
+    // 64-byte rows always use
+    if (a.words == 8 && a.mfma) hipLaunchKernelGGL(k_knn2_mfma, grid, dim3(256), 0, st, a);
     else if (a.words == 8) hipLaunchKernelGGL(k_knn2<8>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_knn2<16>, grid, dim3(256), 0, st, a);
 }
@@ -677,6 +675,7 @@ extern "C" int vo_knn2_hamming_static(vo_ctx* c, const uint8_t* d_q, int nq, con
     a.rev = nullptr;
     a.nq_cap = VO_KNN_STATIC_MAX;
     a.npairs = 1;
+    a.mfma = c->opt_knn_mfma;
     launch_knn2(c->stream, a);
     launch_knn2_merge(c->stream, a);
     hipLaunchKernelGGL(k_keys_to_dmatch, dim3(cdiv(nq, 256)), dim3(256), 0, c->stream, ws, nq, d_out);

@@ -183,6 +183,7 @@ struct KnnArgs {
     uint2* rev;           // [pair][nq_cap] keys of the two nearest queries of every train row (cross only)
     int nq_cap;           // row capacity of part / knn / rev (>= nq, and >= nt with cross)
     int npairs;
+    int mfma;             // 32-byte rows: 1 matrix-core kernel, 0 popcount kernel (vo_ctx::opt_knn_mfma)
 };
 #define VO_KNN_STATIC_MAX 8192  // rows a side of vo_knn2_hamming_static (include/vo_hip.h documents it)
 int knn_static_init(int device);  // address of this device's static matcher workspace (k_match.hip)

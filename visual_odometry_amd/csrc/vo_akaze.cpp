@@ -420,8 +420,7 @@ int vo_akaze_detect_compute(vo_ctx* c, const uint8_t* gray, int w, int h, int st
         }
         return VO_OK;
     };
-    const char* env_graph = getenv("VO_AKAZE_GRAPH");  // read per call: a test switches it inside one process
-    const bool use_graph = !(env_graph && atoi(env_graph) == 0);
+    const bool use_graph = c->opt_akaze_graph != 0;  // VO_OPT_AKAZE_GRAPH
     if (use_graph) {
         vo_ctx::AkGraphKey key;
         memset(&key, 0, sizeof(key));

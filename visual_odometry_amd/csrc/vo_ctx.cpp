@@ -1,4 +1,7 @@
 // vo_ctx.cpp — context lifetime, workspace growth, profiling hooks of libvo_hip.so.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ctx.h"
 
 int vo_ensure(vo_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -161,6 +164,17 @@ int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
     memset(&c->tk_geom, 0, sizeof(c->tk_geom));
     if (limits) c->lim = *limits;
     else vo_limits_default(&c->lim);
+    // schedule switches: the environment is read here, once per context (vo_ctx_set_option changes them later)
+    auto env_int = [](const char* name, int dflt) {
+        const char* e = getenv(name);
+        return e && *e ? atoi(e) : dflt;
+    };
+    c->opt_knn_mfma = env_int("VO_KNN_MFMA", 1) != 0;
+    c->opt_orb_split = env_int("VO_ORB_SPLIT", 0) != 0;
+    c->opt_seq_prefetch = env_int("VO_SEQ_PREFETCH", 0) != 0;
+    c->opt_akaze_graph = env_int("VO_AKAZE_GRAPH", 1) != 0;
+    c->opt_solver = env_int("VO_SOLVER", 0) != 0;
+    c->opt_knn_splits = std::max(0, env_int("VO_KNN_SPLITS", 0));
     if (c->lim.max_points > 65535 || c->lim.max_features > 262143 || c->lim.max_points < 5 ||
         c->lim.max_batch < 2 || c->lim.max_width < 7 || c->lim.max_height < 7) {
         delete c;
@@ -227,6 +241,19 @@ int vo_ctx_set_option(vo_ctx* c, int option, int value) {
         c->sel_cap = value;
         return VO_OK;
     }
+    int* sw = option == VO_OPT_KNN_MFMA ? &c->opt_knn_mfma : option == VO_OPT_ORB_SPLIT ? &c->opt_orb_split
+              : option == VO_OPT_SEQ_PREFETCH ? &c->opt_seq_prefetch : option == VO_OPT_AKAZE_GRAPH ? &c->opt_akaze_graph
+              : option == VO_OPT_SOLVER ? &c->opt_solver : nullptr;
+    if (sw) {
+        if (value != 0 && value != 1) return c->fail(VO_ERR_INVALID, "option %d takes 0 or 1", option);
+        *sw = value;
+        return VO_OK;
+    }
+    if (option == VO_OPT_KNN_SPLITS) {
+        if (value < 0 || value > 32) return c->fail(VO_ERR_INVALID, "VO_OPT_KNN_SPLITS must be in [0, 32]");
+        c->opt_knn_splits = value;
+        return VO_OK;
+    }
     return c->fail(VO_ERR_INVALID, "unknown or read-only option %d", option);
 }
 
@@ -235,6 +262,12 @@ int vo_ctx_get_option(vo_ctx* c, int option, int* value) {
     if (option == VO_OPT_SEL_CAP) *value = c->sel_cap;
     else if (option == VO_OPT_LAST_FLAGS) *value = c->last_flags;
     else if (option == VO_OPT_CAND_CAP) *value = c->max_cand;
+    else if (option == VO_OPT_KNN_MFMA) *value = c->opt_knn_mfma;
+    else if (option == VO_OPT_ORB_SPLIT) *value = c->opt_orb_split;
+    else if (option == VO_OPT_SEQ_PREFETCH) *value = c->opt_seq_prefetch;
+    else if (option == VO_OPT_AKAZE_GRAPH) *value = c->opt_akaze_graph;
+    else if (option == VO_OPT_SOLVER) *value = c->opt_solver;
+    else if (option == VO_OPT_KNN_SPLITS) *value = c->opt_knn_splits;
     else return c->fail(VO_ERR_INVALID, "unknown option %d", option);
     return VO_OK;
 }

@@ -408,8 +408,7 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     // host_selection = the redo of a batch whose first pass already blurred the pyramid
     if (!host_selection)
         launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
-    const char* split_env = getenv("VO_ORB_SPLIT");  // 1: orientation and description as two kernels (read per call)
-    const bool split = split_env && atoi(split_env) != 0;
+    const bool split = c->opt_orb_split != 0;  // orientation and description as two kernels (VO_OPT_ORB_SPLIT)
     if (angles && !split) {
         // d_sel: the device selection's lists flattened by k_sel_flatten, with the rows of flagged frames
         // replaced by the host selection in the redo

@@ -142,7 +142,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
             const int h1 = std::min(H, h0 + size);
             {
                 ProfScope ps(c, VO_PROF_SOLVE);
-                launch_solve5(st, h0, h1, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs);
+                launch_solve5(st, h0, h1, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs, c->opt_solver);
             }
             launch_score(st, h0, h1, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<int>(), H, npairs);
             launch_replay(st, h0, h1, S, nmodels, c->d_counts.as<int>(), H, prob, npairs);
@@ -152,7 +152,7 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
     } else {
         {
             ProfScope ps(c, VO_PROF_SOLVE);
-            launch_solve5(st, 0, niters, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs);
+            launch_solve5(st, 0, niters, S, samples, c->samples->iters, x1, x2, n_cap, models, nmodels, H, npairs, c->opt_solver);
         }
         launch_lmeds(st, S, x1, x2, n_cap, models, nmodels, c->d_counts.as<double>(), H, niters, npairs);
     }

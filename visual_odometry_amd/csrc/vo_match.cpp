@@ -29,12 +29,12 @@ int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q
     a.words = words;
     a.cross = cross ? 1 : 0;
     const int dirs = cross ? 2 : 1;
-    // tuning hook for tools/bench_knn.py
-    static const int env_s = getenv("VO_KNN_SPLITS") ? atoi(getenv("VO_KNN_SPLITS")) : 0;
+    const int env_s = c->opt_knn_splits;  // tuning hook for tools/bench_knn.py
     a.splits = knn_splits(cross ? std::max(nq, nt) : nq, cross ? std::min(nq, nt) : nt, npairs, dirs);
     if (env_s) a.splits = std::max(1, std::min(env_s, std::max(nt, 1) / 64));
     a.nq_cap = nq_cap;
     a.npairs = npairs;
+    a.mfma = c->opt_knn_mfma;
     if (a.splits > 1) VO_TRY(vo_ensure(c, c->d_part, (size_t)npairs * dirs * a.splits * nq_cap * sizeof(uint2)));
     VO_TRY(vo_ensure(c, c->d_knn, (size_t)npairs * nq_cap * sizeof(uint2)));
     if (cross) VO_TRY(vo_ensure(c, c->d_rev, (size_t)npairs * nq_cap * sizeof(uint2)));

@@ -314,6 +314,7 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
     s->submit_ms = s->wait_ms = 0;
     s->chunks = nchunks;
     for (auto& P : s->pre) P.chunk[0] = P.chunk[1] = -1;  // nothing of this run is on the device yet
+    const bool prefetch = s->ctx[0]->opt_seq_prefetch != 0;
     auto collect = [&](int k) {
         const auto t0 = clk::now();
         const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], ch[(size_t)k].res, ch[(size_t)k].out, ch[(size_t)k].pair0));
@@ -343,11 +344,9 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
         }
         // Pinned frames go up on the chunk's own stream in front of its kernels: the copies of the other chunks
         // overlap them, and no further streams compete for the process's hardware queues (108 k pairs/s against
-        // 87 k with four chunks in flight).  VO_SEQ_PREFETCH=1: the earlier scheme, every context sends chunk
-        // k + S ahead of time on a copy stream of its own into a second image buffer; read per run.
-        static const char* pf_env = nullptr;
-        if (k == 0) pf_env = getenv("VO_SEQ_PREFETCH");
-        const bool prefetch = pf_env && atoi(pf_env) != 0;
+        // 87 k with four chunks in flight).  VO_OPT_SEQ_PREFETCH = 1 (taken from the runner's first context at the
+        // start of the run): the earlier scheme, every context sends chunk k + S ahead of time on a copy stream of
+        // its own into a second image buffer.
         if (mem == VO_MEM_HOST_PINNED && stride == w && frame_stride == img && prefetch) {
             vo_seq::Prefetch& P = s->pre[slot];
             const size_t need = (size_t)(B + 1) * img;
