@@ -255,6 +255,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-8k", action="store_true", help="skip the 8192 x 8192 matcher side measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the frames-in-pinned-host-memory side measurement")
+    ap.add_argument("--no-configs4", action="store_true", help="N = 1: skip the 22-sequence configs[4] side run")
+    ap.add_argument("--no-single-pair", action="store_true", help="skip the configs[1] single-pair latency measurement")
+    ap.add_argument("--no-lk", action="store_true", help="skip the default (FAST -> LK -> LMedS) pipeline measurement")
+    ap.add_argument("--lk-sequences", type=int, default=8, help="independent sequences of the concurrent LK run")
     ap.add_argument("--workload", choices=["auto", "configs4"], default="auto",
                     help="auto: configs[3] on one GPU, configs[4] on several; configs4: the 22 sequences also at N = 1")
     ap.add_argument("--dry-run", action="store_true",
@@ -300,7 +304,8 @@ def main():
                                   "--warmup", "2", "--frames", str(args.frames), "--base-frames",
                                   str(args.base_frames), "--chunk", str(args.chunk), "--nfeatures",
                                   str(args.nfeatures), "--max-iters", str(args.max_iters), "--no-cpu-baseline",
-                                  "--no-8k", "--no-pcie", "--no-default-queues"],
+                                  "--no-8k", "--no-pcie", "--no-default-queues", "--no-configs4", "--no-single-pair",
+                                  "--no-lk"],
                                  env=env, capture_output=True, text=True, timeout=150)
             child = json.loads(out.stdout.strip().splitlines()[-1])
             default_queues = {"value": child["value"], "unit": "frame-pairs/s",
@@ -323,6 +328,11 @@ def main():
         imbalance = max(loads) / (sum(loads) / world)
     total_pairs_per_step = sum(n - 1 for n in lengths)
     lmax = max([n for _, n in my_seqs] + [2])
+    # N = 1 also runs configs[4] (the 22 sequences through one pipeline) beside its headline: the buffer then
+    # holds the longest of them
+    side_configs4 = world == 1 and not multi and not args.no_configs4 and not args.dry_run
+    if side_configs4:
+        lmax = max(lmax, max(shard.KITTI_LENGTHS))
 
     # ---- synthetic input: rendered in forked workers before anything touches the GPU -------------------
     base_n = max(2, min(args.base_frames, lmax))
@@ -570,6 +580,99 @@ def main():
                     "note": "vo_akaze_detect_compute on one 1241x376 frame, host pointers in and out (key-frame "
                             "operation of the BA front end, not part of `value`)"}
 
+        # ---- BASELINE configs[4] on this ONE GPU: the 22 KITTI-shaped sequences through one pipeline
+        # (vo_seq_run_multi), every sequence a window of the resident buffer.  The base of the 1 -> 8 curve.
+        configs4 = None
+        if side_configs4:
+            kl = list(shard.KITTI_LENGTHS)
+            c4 = [(d_seq.data_ptr(), n) for n in kl]
+            c4_out = [(out_m[: n - 1], out_im[: n - 1], out_pm[: n - 1]) for n in kl]
+            seq.run_multi(c4, w, h, w, w * h, K, params, outputs=c4_out)
+            torch.cuda.synchronize()
+            c4_steps = max(2, args.steps // 5)
+            tc = time.perf_counter()
+            for _ in range(c4_steps):
+                r4 = seq.run_multi(c4, w, h, w, w * h, K, params, outputs=c4_out)
+            tc = time.perf_counter() - tc
+            c4_pairs = sum(n - 1 for n in kl)
+            c4_ok = sum(1 for r, n in zip(r4, kl) for p in range(n - 1) if r[p].status == 0)
+            imb = {}
+            for g in (1, 2, 4, 8):
+                loads = [sum(kl[i] - 1 for i in a) for a in shard.lpt_assign(kl, g)]
+                imb[str(g)] = max(loads) / (sum(loads) / g)
+            configs4 = {"value": c4_steps * c4_pairs / tc, "unit": "frame-pairs/s", "steps": c4_steps,
+                        "ms_per_step": tc / c4_steps * 1e3, "sequences": len(kl), "frames_per_step": sum(kl),
+                        "pairs_per_step": c4_pairs, "pairs_with_pose": c4_ok, "lpt_imbalance": imb,
+                        "note": "BASELINE configs[4] at N = 1: what `bench.py --gpus 1 --workload configs4` runs, beside "
+                                "the configs[3] headline; lpt_imbalance = max rank load / mean for 1, 2, 4, 8 ranks"}
+
+        # ---- BASELINE configs[1]: ONE frame pair (2 frames, 1241x376, 2k ORB) as latency, not throughput ------
+        single = None
+        if world == 1 and not args.no_single_pair:
+            def med(fn, reps=60, skip=10):
+                ts = []
+                for i in range(reps):
+                    t0 = time.perf_counter()
+                    fn(i)
+                    ts.append(time.perf_counter() - t0)
+                return float(np.median(ts[skip:])) * 1e3
+
+            nb = min(40, n0 - 1)
+            ms_res = med(lambda i: ctx.pairs_run_dev(d_seq.data_ptr() + (i % nb) * w * h, 2, w, h, w, w * h, K, params))
+            orbp = api.orb_params(args.nfeatures)
+
+            def host_pair(i):
+                f0, f1 = frames[idx[i % nb]], frames[idx[i % nb + 1]]
+                k0, d0 = ctx.orb_detect_compute(f0, orbp)
+                k1, d1 = ctx.orb_detect_compute(f1, orbp)
+                knn, nv = ctx.knn2_hamming(d0, d1)
+                good = ctx.match_filter(knn, nv, k0, k1, 0.7, 200.0)
+                p0 = np.stack([k0["x"][good["queryIdx"]], k0["y"][good["queryIdx"]]], 1)
+                p1 = np.stack([k1["x"][good["trainIdx"]], k1["y"][good["trainIdx"]]], 1)
+                rc, E, mask = ctx.find_essential(p0, p1, K, max_iters=args.max_iters)
+                if rc == 0:
+                    ctx.recover_pose(E, p0, p1, K, 200.0, mask)
+
+            ms_host = med(host_pair, reps=40, skip=8)
+            ctx.prof_enable(True)
+            for which in (0, 1, 2, 3):
+                ctx.prof_get(which, True)
+            for i in range(20):
+                ctx.pairs_run_dev(d_seq.data_ptr() + (i % nb) * w * h, 2, w, h, w, w * h, K, params)
+            kus = {}
+            for name, which in (("features_2_frames", 3), ("fast_nms", 1), ("knn2", 0), ("solve5_rounds", 2)):
+                cnt, ms = ctx.prof_get(which)
+                kus[name] = ms / 20 * 1e3
+            ctx.prof_enable(False)
+            single = {"ms_resident": ms_res, "ms_host_pointers": ms_host, "kernel_us": kus,
+                      "note": "configs[1]: 2 frames through vo_pairs_run_dev (frames in HBM, results on the host), median "
+                              "of 50; ms_host_pointers: the reference's own call sequence through the host-pointer entry "
+                              "points (detectAndCompute x2, knnMatch, filter, findEssentialMat, recoverPose: six "
+                              "synchronous calls, numpy glue included); kernel_us: HIP events around the stage's launches"}
+
+        # ---- the reference's DEFAULT pipeline (src/visual_odometry/visual_odometry.cpp:33-49: FAST when lost ->
+        # pyramidal LK -> removePoints -> findEssentialMat(LMEDS) -> recoverPose -> chaining) through the C++
+        # driver of the host mirror, one frame at a time; then S independent sequences side by side
+        lk = None
+        if world == 1 and not args.no_lk:
+            from visual_odometry_amd import host_api
+
+            nlk = min(len(frames), 240)
+            wu = min(40, nlk // 3)
+            host_api.timing_enable(True)
+            wall1, timed1, _ = host_api.run_concurrent(K, [frames[:nlk]], warmup=wu)
+            stages = {k: round(v[1], 1) for k, v in host_api.timing_get().items()}
+            host_api.timing_enable(False)
+            S = max(1, args.lk_sequences)
+            wallS, timedS, _ = host_api.run_concurrent(K, [frames[:nlk]] * S, warmup=wu)
+            lk = {"frames_per_s": timed1 / wall1, "per_stage_us": stages,
+                  "concurrent": {"sequences": S, "frames_per_s": timedS / wallS,
+                                 "speedup_over_one_sequence": (timedS / wallS) / (timed1 / wall1)},
+                  "frames_per_sequence": nlk, "warmup_frames": wu,
+                  "note": "VisualOdometry::addImage of the host mirror (C++), 1241x376 frames in host memory, 3-channel "
+                          "LK sums as the reference's CPU build; `concurrent`: S drivers on S host threads, each with "
+                          "its own contexts / HIP streams (vo_host_vo_run_concurrent)"}
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(frames, K, args.nfeatures, args.max_iters)
@@ -607,6 +710,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "matcher_8k": matcher_8k,
+            "configs4_one_gpu": configs4,
+            "single_pair": single,
+            "lk_pipeline": lk,
             "side": side,
             "default_queues": default_queues,
             "detector_roofline": detector,

@@ -293,8 +293,18 @@ static void build_pyramid(const uint8_t* gray, int w, int h, int stride, const O
     }
 }
 
-// KeyPointsFilter::retainBest (3.4.2 form): nth_element at n, threshold = kp[n-1].response,
-// partition the tail on response >= threshold.  The permutation is libstdc++'s.
+// KeyPointsFilter::retainBest: nth_element, threshold = kp[n-1].response, partition the tail on
+// response >= threshold.  The permutation is libstdc++'s.  Where nth_element splits is VERSION-SENSITIVE and
+// therefore a named option (vo_oracle_set_retain_best_split): OpenCV 3.4.2 - the release the reference pins,
+// README.md:23-25 - calls nth_element(begin, begin + n, end), so kp[n-1] is merely one of the n best, not
+// the n-th; later OpenCV releases call nth_element(begin, begin + n - 1, end).  The two leave different
+// permutations (and, on ties at the threshold, can keep different sets), so every keypoint index differs.
+// Default and product path: the 3.4.2 form.  tests/test_cv2_pin.py picks the form from cv2.__version__.
+static int g_retain_split = VO_ORACLE_RETAIN_CV342;
+extern "C" void vo_oracle_set_retain_best_split(int mode) {
+    g_retain_split = mode == VO_ORACLE_RETAIN_LATER ? VO_ORACLE_RETAIN_LATER : VO_ORACLE_RETAIN_CV342;
+}
+extern "C" int vo_oracle_get_retain_best_split(void) { return g_retain_split; }
 struct RespGreater {
     bool operator()(const vo_keypoint& a, const vo_keypoint& b) const {
         return a.response > b.response;
@@ -306,7 +316,8 @@ static void retain_best(std::vector<vo_keypoint>& kps, int n_points) {
             kps.clear();
             return;
         }
-        std::nth_element(kps.begin(), kps.begin() + n_points, kps.end(), RespGreater());
+        std::nth_element(kps.begin(), kps.begin() + n_points - (g_retain_split == VO_ORACLE_RETAIN_LATER ? 1 : 0),
+                         kps.end(), RespGreater());
         float ambiguous = kps[n_points - 1].response;
         auto new_end = std::partition(kps.begin() + n_points, kps.end(),
                                       [ambiguous](const vo_keypoint& k) { return k.response >= ambiguous; });

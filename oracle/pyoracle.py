@@ -218,6 +218,19 @@ def sample_subsets(seed, npoints, niters):
     return idx
 
 
+RETAIN_CV342, RETAIN_LATER = 0, 1
+
+
+def set_retain_best_split(mode):
+    """KeyPointsFilter::retainBest's nth_element position: RETAIN_CV342 (begin + n, the reference's OpenCV
+    3.4.2, the default) or RETAIN_LATER (begin + n - 1, later OpenCV releases).  Process-wide."""
+    lib().vo_oracle_set_retain_best_split(int(mode))
+
+
+def get_retain_best_split():
+    return lib().vo_oracle_get_retain_best_split()
+
+
 def five_point(x1, x2):
     x1 = np.ascontiguousarray(x1, np.float64)
     x2 = np.ascontiguousarray(x2, np.float64)

@@ -37,6 +37,12 @@ int vo_oracle_resize_linear_exact(const uint8_t* src, int sw, int sh, int sstrid
 int vo_oracle_gauss7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
 
 void vo_oracle_orb_params_default(vo_orb_params* p, int nfeatures);
+/* Where KeyPointsFilter::retainBest's nth_element splits: OpenCV 3.4.2 (the reference's pin) uses begin + n,
+ * later releases begin + n - 1; process-wide switch of the ORACLE only (the product implements the 3.4.2 form). */
+#define VO_ORACLE_RETAIN_CV342 0
+#define VO_ORACLE_RETAIN_LATER 1
+void vo_oracle_set_retain_best_split(int mode);
+int vo_oracle_get_retain_best_split(void);
 
 /* ORB pyramid geometry: per level width/height/scale/feature quota. Returns nlevels. */
 int vo_oracle_orb_layout(int w, int h, const vo_orb_params* p, int* lw, int* lh, float* lscale,

@@ -26,12 +26,14 @@ def _same(a, b):
         assert np.array_equal(a[f], b[f]), f
 
 
-def test_static_entry_point_equals_the_allocating_one_twice_in_a_row(vo):
+def test_static_entry_point_equals_the_allocating_one_twice_in_a_row(vo, oracle):
     q, t = synth.matcher_descriptors(8192)
     want, _ = vo.knn2_hamming(q, t)
     _same(_static(vo, q, t), want)                      # 8192 x 8192: train range in 12 splits
     want2, _ = vo.knn2_hamming(q[:1000], t[:777])
-    _same(_static(vo, q[:1000], t[:777]), want2)        # smaller, right after: nothing stale
+    got2 = _static(vo, q[:1000], t[:777])
+    _same(got2, want2)                                  # smaller, right after: nothing stale
+    _same(got2, oracle.knn2_hamming(q[:1000], t[:777])[0])  # and the oracle's table itself, not only the sibling's
     want3, _ = vo.knn2_hamming(q[:70], t[:1])
     got3 = _static(vo, q[:70], t[:1])                   # fewer than two train rows: -1 / FLT_MAX
     _same(got3, want3)

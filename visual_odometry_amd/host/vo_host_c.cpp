@@ -3,7 +3,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
+#include <string>
+#include <thread>
 
 #include "bundle_adjustment.h"
 #include "host_internal.h"
@@ -64,6 +69,94 @@ int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, doubl
         set_err(err, err_cap, e.what());
         return -1;
     }
+}
+
+int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t scale_seed, int tracker_channels,
+                              const uint8_t* const* frames, const int* n_frames, int n_seq, int w, int h, int warmup,
+                              double* const* poses, double* wall_seconds, long* timed_frames, char* err, int err_cap) {
+    if (!K || !frames || !n_frames || n_seq < 1 || n_seq > 64 || w <= 0 || h <= 0 || warmup < 0) {
+        set_err(err, err_cap, "vo_host_vo_run_concurrent: bad argument");
+        return -1;
+    }
+    vo::Matd Km(3, 3);
+    for (int i = 0; i < 9; i++) Km.d[i] = K[i];
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    std::string first_error;
+    using clk = std::chrono::steady_clock;
+    clk::time_point t_start;
+    std::vector<clk::time_point> t_end((size_t)n_seq);
+    long timed = 0;
+    auto run = [&](int s) {
+        try {
+            setScaleSeed(scale_seed + (uint32_t)s);  // this thread's generator
+            VisualOdometry vo(Km, (size_t)min_tracked_points, false, tracker_channels);
+            vo::Matd pose = vo::Matd::eye(3, 4);
+            const size_t img = (size_t)w * h;
+            auto feed = [&](int f) {
+                vo::Image im;
+                im.width = w;
+                im.height = h;
+                im.px.assign(frames[s] + (size_t)f * img, frames[s] + (size_t)(f + 1) * img);
+                vo.addImage(im, &pose, nullptr);
+                if (poses && poses[s])
+                    for (int i = 0; i < 12; i++) poses[s][(size_t)f * 12 + i] = pose.d[i];
+            };
+            const int nw = std::min(warmup, n_frames[s]);
+            for (int f = 0; f < nw; f++) feed(f);
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                if (++arrived == n_seq) {
+                    t_start = clk::now();
+                    cv.notify_all();
+                } else {
+                    cv.wait(lock, [&] { return arrived >= n_seq; });
+                }
+                timed += n_frames[s] - nw;
+            }
+            for (int f = nw; f < n_frames[s]; f++) feed(f);
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (first_error.empty()) first_error = e.what();
+            if (arrived < n_seq) {  // never leave the others waiting at the barrier
+                arrived = n_seq;
+                t_start = clk::now();
+                cv.notify_all();
+            }
+        }
+        t_end[(size_t)s] = clk::now();
+    };
+    std::vector<std::thread> th;
+    for (int s = 0; s < n_seq; s++) th.emplace_back(run, s);
+    for (auto& t : th) t.join();
+    if (!first_error.empty()) {
+        set_err(err, err_cap, first_error.c_str());
+        return -1;
+    }
+    clk::time_point last = t_end[0];
+    for (const auto& t : t_end) last = std::max(last, t);
+    if (wall_seconds) *wall_seconds = std::chrono::duration<double>(last - t_start).count();
+    if (timed_frames) *timed_frames = timed;
+    return 0;
+}
+
+void vo_host_timing_enable(int on) { g_timers.on = on != 0; }
+
+void vo_host_timing_reset(void) {
+    for (int i = 0; i < StageTimers::N; i++) {
+        g_timers.sec[i] = 0;
+        g_timers.calls[i] = 0;
+    }
+}
+
+int vo_host_timing_get(int i, const char** name, long* calls, double* us_each) {
+    if (i >= 0 && i < StageTimers::N) {
+        if (name) *name = g_timers.names[i];
+        if (calls) *calls = g_timers.calls[i];
+        if (us_each) *us_each = g_timers.calls[i] ? g_timers.sec[i] / g_timers.calls[i] * 1e6 : 0.0;
+    }
+    return StageTimers::N;
 }
 
 int vo_host_vo_state(vo_host_vo* v, int* full, int* tracking, int* n_points, int* n_mask, float* scale) {

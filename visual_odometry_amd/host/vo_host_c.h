@@ -24,6 +24,25 @@ void vo_host_vo_destroy(vo_host_vo* v);
  * Returns 0, or -1 with the message in err. */
 int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, double* pose, char* err, int err_cap);
 
+/* S independent VisualOdometry drivers side by side, one host thread (and its own contexts / HIP streams) each:
+ * the frames of one sequence are serial through the tracked points and the pose chain, sequences are not
+ * ("frame-pair batching").  Driver s is fed frames[s][0 .. n_frames[s]) (w x h gray, tightly
+ * packed, HOST memory) through addImage exactly as vo_host_vo_add_image would.  Every driver first runs its
+ * first `warmup` frames (context creation, sample table, buffer growth), then all meet at a barrier and the
+ * rest is timed: *wall_seconds is the time until the last driver finishes, *timed_frames the frames inside it.
+ * poses: NULL or n_seq pointers to n_frames[s] x 12 doubles.  Same results as n_seq separate drivers
+ * (getScale's generator is per thread, seeded scale_seed + s).  Returns 0, or -1 with the message in err. */
+int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t scale_seed, int tracker_channels,
+                              const uint8_t* const* frames, const int* n_frames, int n_seq, int w, int h, int warmup,
+                              double* const* poses, double* wall_seconds, long* timed_frames, char* err, int err_cap);
+
+/* Wall time per stage of the per-frame driver (what VO_HOST_TIMING=1 prints at exit), readable by a harness.
+ * One set of counters per process, not synchronised: meaningful for a single driver thread only.
+ * vo_host_timing_get: stage i -> name, calls, microseconds per call; returns the number of stages. */
+void vo_host_timing_enable(int on);
+void vo_host_timing_reset(void);
+int vo_host_timing_get(int i, const char** name, long* calls, double* us_each);
+
 /* State of the last addImage for parity checks: counts first (n_prev == n_cur), then the arrays
  * (any pointer may be NULL; capacities are the counts returned by the first call). */
 int vo_host_vo_state(vo_host_vo* v, int* full, int* tracking, int* n_points, int* n_mask, float* scale);

@@ -13,7 +13,8 @@ SYMBOLS = ["vo_host_vo_create", "vo_host_vo_destroy", "vo_host_vo_add_image", "v
            "vo_host_vo_arrays", "vo_host_load_calibration", "vo_host_load_poses", "vo_host_save_poses",
            "vo_host_remove_points", "vo_host_create_match_matrix", "vo_host_ba_create", "vo_host_ba_create_ex", "vo_host_ba_desc_bytes", "vo_host_ba_destroy",
            "vo_host_ba_add_key_frame", "vo_host_ba_counts", "vo_host_ba_features", "vo_host_ba_pair",
-           "vo_host_ba_match_matrix", "vo_host_ba_points"]
+           "vo_host_ba_match_matrix", "vo_host_ba_points", "vo_host_vo_run_concurrent", "vo_host_timing_enable",
+           "vo_host_timing_reset", "vo_host_timing_get"]
 _lib = None
 
 
@@ -44,6 +45,13 @@ def lib():
         _lib.vo_host_ba_pair.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
         _lib.vo_host_ba_match_matrix.argtypes = [C.c_void_p, C.c_void_p]
         _lib.vo_host_ba_points.argtypes = [C.c_void_p] * 4
+        _lib.vo_host_vo_run_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_char_p, C.c_int]
+        _lib.vo_host_timing_enable.argtypes = [C.c_int]
+        _lib.vo_host_timing_enable.restype = None
+        _lib.vo_host_timing_reset.restype = None
+        _lib.vo_host_timing_get.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -101,6 +109,48 @@ class HostVisualOdometry:
         self.L.vo_host_vo_arrays(self.h, _p(p0), _p(p1), _p(mask), _p(E), _p(R), _p(t), _p(p3))
         out.update(prev_points=p0[:n], points=p1[:n], mask=mask[:nm], E=E, local_R=R, local_t=t, points_3d=p3[:nm])
         return out
+
+
+def run_concurrent(K, sequences, min_tracked_points=750, scale_seed=1234, tracker_channels=3, warmup=0,
+                   want_poses=False):
+    """S VisualOdometry drivers side by side, one host thread each (vo_host_vo_run_concurrent).  sequences: list
+    of (n, h, w) uint8 arrays of one frame size.  Returns (wall seconds of the timed part, frames in it, poses or
+    None)."""
+    L = lib()
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    seqs = [np.ascontiguousarray(s, dtype=np.uint8) for s in sequences]
+    n = len(seqs)
+    h, w = seqs[0].shape[1:]
+    assert all(s.ndim == 3 and s.shape[1:] == (h, w) for s in seqs)
+    ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in seqs])
+    counts = (C.c_int * n)(*[len(s) for s in seqs])
+    poses = [np.zeros((len(s), 12)) for s in seqs] if want_poses else None
+    pp = (C.c_void_p * n)(*[p.ctypes.data for p in poses]) if want_poses else None
+    wall, timed = C.c_double(0), C.c_long(0)
+    err = C.create_string_buffer(512)
+    rc = L.vo_host_vo_run_concurrent(_p(K), int(min_tracked_points), int(scale_seed), int(tracker_channels), ptrs, counts,
+                                     n, w, h, int(warmup), pp, C.byref(wall), C.byref(timed), err, 512)
+    if rc != 0:
+        raise RuntimeError("run_concurrent: " + err.value.decode())
+    return wall.value, timed.value, poses
+
+
+def timing_enable(on=True):
+    lib().vo_host_timing_enable(int(bool(on)))
+    lib().vo_host_timing_reset()
+
+
+def timing_get():
+    """{stage name: (calls, microseconds per call)} of the per-frame driver since timing_enable()."""
+    L = lib()
+    out = {}
+    name, calls, us = C.c_char_p(), C.c_long(0), C.c_double(0)
+    n = L.vo_host_timing_get(0, C.byref(name), C.byref(calls), C.byref(us))
+    for i in range(n):
+        L.vo_host_timing_get(i, C.byref(name), C.byref(calls), C.byref(us))
+        if calls.value:
+            out[name.value.decode()] = (calls.value, us.value)
+    return out
 
 
 def load_calibration(path, line_number=0):
