@@ -289,7 +289,7 @@ int vo_prof_enable(vo_ctx* ctx, int on);
 #define VO_OPT_CAND_CAP 2 /* read only: FAST candidates per frame the lists hold now (they grow on demand) */
 /* Switches between kernel schedules that give identical results (the parity tests flip them).  Each starts from
  * the environment variable of the same name without the OPT_ (VO_KNN_MFMA, VO_ORB_SPLIT, VO_SEQ_PREFETCH,
- * VO_AKAZE_GRAPH, VO_SOLVER, VO_KNN_SPLITS), read ONCE when the context is created, never per call. */
+ * VO_AKAZE_GRAPH, VO_SOLVER, VO_KNN_SPLITS, VO_LK_GENERIC), read ONCE when the context is created, never per call. */
 #define VO_OPT_KNN_MFMA 3     /* 1 (default): 32-byte rows on the matrix-core matcher; 0: popcount kernel */
 #define VO_OPT_ORB_SPLIT 4    /* 0 (default): orientation + description fused; 1: two kernels */
 #define VO_OPT_SEQ_PREFETCH 5 /* 0 (default): pinned frames go up on the chunk's stream; 1: copy stream per context */
@@ -298,6 +298,8 @@ int vo_prof_enable(vo_ctx* ctx, int on);
                                * group, 1 one per lane.  Fixed per context: it never depends on the batch size, so a
                                * pair's E / masks / pose do not depend on how many pairs share its launch. */
 #define VO_OPT_KNN_SPLITS 8   /* 0 (default): automatic; > 0: train-range splits of a single 2-NN problem */
+#define VO_OPT_LK_GENERIC 9   /* 0 (default): cv's default 21 x 21 LK window on the kernel specialised for it; 1: on the
+                               * kernels every other window size uses (VO_LK_GENERIC) */
 int vo_ctx_set_option(vo_ctx* ctx, int option, int value);
 int vo_ctx_get_option(vo_ctx* ctx, int option, int* value);
 

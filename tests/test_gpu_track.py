@@ -49,6 +49,32 @@ def test_lk_track_kitti_shaped(vo, oracle, frames, channels):
     assert gs.mean() > 0.5
 
 
+def test_lk_default_window_kernel_equals_the_generic_kernels(vo, oracle, frames):
+    """The default 21 x 21 window runs on k_lk_track_21 (a lane owns seven pixels of a window row: two 8-byte loads
+    per resampling); VO_OPT_LK_GENERIC = 1 sends it through k_lk_track_small, the kernel of every other window
+    size.  The window sums are exact integers, so both must return the same bits - and the oracle's - also for
+    points whose windows hang over the image edge or start outside it."""
+    from visual_odometry_amd import api
+
+    fr, _, _ = frames
+    kp = vo.fast_detect(fr[0], 20, True)
+    p0 = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+    edge = np.array([[0, 0], [1240, 375], [-5.5, 100.25], [1244.75, 10], [600.5, -9], [3.25, 372.5], [-30, -30],
+                     [620, 400]], np.float32)
+    p0 = np.concatenate([p0, edge])
+    prm = api.lk_params()
+    a1, as_ = vo.lk_track(fr[0], fr[2], p0, prm)  # two frames apart: more iterations, some lost points
+    vo.set_option(api.OPT_LK_GENERIC, 1)
+    try:
+        b1, bs = vo.lk_track(fr[0], fr[2], p0, prm)
+    finally:
+        vo.set_option(api.OPT_LK_GENERIC, 0)
+    assert np.array_equal(as_, bs) and np.array_equal(a1, b1)
+    o1, os_ = oracle.lk_track(fr[0], fr[2], p0, oracle.lk_params())
+    assert np.array_equal(as_, os_) and np.array_equal(a1, o1)
+    assert 0.3 < as_.mean() < 1.0
+
+
 def test_lk_track_chained_with_cached_pyramid(vo, oracle, frames):
     from visual_odometry_amd import api
 

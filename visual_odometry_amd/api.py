@@ -18,7 +18,7 @@ DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4")
 
 LMEDS, RANSAC = 4, 8
 OPT_SEL_CAP, OPT_LAST_FLAGS, OPT_CAND_CAP = 0, 1, 2
-OPT_KNN_MFMA, OPT_ORB_SPLIT, OPT_SEQ_PREFETCH, OPT_AKAZE_GRAPH, OPT_SOLVER, OPT_KNN_SPLITS = 3, 4, 5, 6, 7, 8
+OPT_KNN_MFMA, OPT_ORB_SPLIT, OPT_SEQ_PREFETCH, OPT_AKAZE_GRAPH, OPT_SOLVER, OPT_KNN_SPLITS, OPT_LK_GENERIC = 3, 4, 5, 6, 7, 8, 9
 VO_OK, VO_ERR_INVALID, VO_ERR_CAPACITY, VO_ERR_DEVICE, VO_ERR_FAILED = 0, 1, 2, 3, 4
 
 

@@ -105,6 +105,7 @@ struct vo_ctx {
     int opt_seq_prefetch = 0;  // 1: pinned frames prefetched on a copy stream of the context's own
     int opt_akaze_graph = 1;   // AKAZE scale space replayed from a captured hipGraph (0: plain launches)
     int opt_solver = 0;        // five-point solver of findEssentialMat: 0 one hypothesis per 16-lane group, 1 per lane
+    int opt_lk_generic = 0;    // 1: the default 21 x 21 LK window through the generic kernels
     int opt_knn_splits = 0;    // > 0: train-range splits of a single 2-NN problem (tuning hook)
 
     PyrGeom geom;  // host copy of d_geom

@@ -397,6 +397,160 @@ __global__ __launch_bounds__(256) void k_lk_track_small(TrackGeom g, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------
+// cv's default 21 x 21 window (what the reference tracks with, src/features/feature_tracker.cpp:6): lane 3 r + s
+// owns the seven pixels 7 s .. 7 s + 6 of window row r.  Their 2 x 2 bilinear taps are the bytes 7 s .. 7 s + 7 of
+// rows r and r + 1, i.e. TWO unaligned 8-byte loads per resampling of J where k_lk_track_small issues 28 byte
+// loads (its items are 64 pixels apart, so no two share a load); the derivative samples of the I window are
+// two 16-byte loads per row.  That kernel is bound by the number of load instructions the texture path takes
+// per iteration (3 000 waves x 4 levels x up to 30 iterations x 32 loads), not by their bytes.  Same integer
+// sums (any order gives the same total), same float expressions: identical results.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ uint2 lk_load8(const uint8_t* p) {  // 8 bytes at any alignment
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ int lk_byte(const uint2& v, int j) {  // byte j (0..7), j known at compile time
+    return (int)(((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xffu);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_lk_track_21(TrackGeom g, const uint8_t* __restrict__ pyrI,
+                                                     const short2* __restrict__ deriv,
+                                                     const uint8_t* __restrict__ pyrJ,
+                                                     const float2* __restrict__ prev_pts,
+                                                     float2* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                                     int n, LkArgs a) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wv;
+    if (pt >= n) return;  // a whole wave leaves; the kernel has no block-wide barrier
+    constexpr int ww = 21, wh = 21, NP = 7;
+    const bool live = lane < 63;
+    const int r = live ? (lane * 21846) >> 16 : 0;  // lane / 3 for lane < 64
+    const int c0 = live ? NP * (lane - 3 * r) : 0;
+    const float2 p = prev_pts[pt];
+    const float half_x = (ww - 1) * 0.5f, half_y = (wh - 1) * 0.5f;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const long long cn = a.channels;
+    float2 np = make_float2(0.f, 0.f);
+    bool ok = true;
+    for (int level = g.nlevels - 1; level >= 0; level--) {
+        const TrackLevel L = g.lv[level];
+        const float sc = __int_as_float((127 - level) << 23);  // (float)(1. / (1 << level))
+        float px = p.x * sc, py = p.y * sc;
+        if (level == g.nlevels - 1) np = make_float2(px, py);
+        else np = make_float2(np.x * 2.f, np.y * 2.f);
+        px -= half_x;
+        py -= half_y;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -ww || ipx >= L.w || ipy < -wh || ipy >= L.h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float fa = px - ipx, fb = py - ipy;
+        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        const int pitch = L.pitch;
+        const int off = __mul24(r, pitch) + c0;  // the lane's first pixel inside a window
+        int Iw[NP], Dx[NP], Dy[NP];
+        int sA11 = 0, sA12 = 0, sA22 = 0;  // per lane: NP terms below 2^25
+        {
+            const uint8_t* I0 = tk_px(pyrI, L) + (ptrdiff_t)ipy * pitch + ipx + off;
+            const short2* D0 = deriv + L.offset + (size_t)(ipy + TK_PAD) * pitch + TK_PAD + ipx + off;
+            const uint2 s0 = lk_load8(I0), s1 = lk_load8(I0 + pitch);
+            uint4 d0[2], d1[2];  // (dx, dy) of the eight pixels of row r / row r + 1
+            __builtin_memcpy(&d0[0], D0, 16);
+            __builtin_memcpy(&d0[1], D0 + 4, 16);
+            __builtin_memcpy(&d1[0], D0 + pitch, 16);
+            __builtin_memcpy(&d1[1], D0 + pitch + 4, 16);
+            const uint32_t* e0 = reinterpret_cast<const uint32_t*>(d0);
+            const uint32_t* e1 = reinterpret_cast<const uint32_t*>(d1);
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const int ival = TK_DESCALE(__mul24(lk_byte(s0, j), iw00) + __mul24(lk_byte(s0, j + 1), iw01) +
+                                                __mul24(lk_byte(s1, j), iw10) + __mul24(lk_byte(s1, j + 1), iw11),
+                                            W_BITS - 5);
+                const int x00 = (int)(short)(e0[j] & 0xffff), y00 = (int)e0[j] >> 16;
+                const int x01 = (int)(short)(e0[j + 1] & 0xffff), y01 = (int)e0[j + 1] >> 16;
+                const int x10 = (int)(short)(e1[j] & 0xffff), y10 = (int)e1[j] >> 16;
+                const int x11 = (int)(short)(e1[j + 1] & 0xffff), y11 = (int)e1[j + 1] >> 16;
+                int ixval = TK_DESCALE(__mul24(x00, iw00) + __mul24(x01, iw01) + __mul24(x10, iw10) + __mul24(x11, iw11),
+                                       W_BITS);
+                int iyval = TK_DESCALE(__mul24(y00, iw00) + __mul24(y01, iw01) + __mul24(y10, iw10) + __mul24(y11, iw11),
+                                       W_BITS);
+                if (!live) ixval = iyval = 0;  // the idle lane adds nothing anywhere below
+                Iw[j] = ival;
+                Dx[j] = ixval;
+                Dy[j] = iyval;
+                sA11 += __mul24(ixval, ixval);
+                sA12 += __mul24(ixval, iyval);
+                sA22 += __mul24(iyval, iyval);
+            }
+        }
+        const long long iA11 = lk_wave_sum(sA11), iA12 = lk_wave_sum(sA12), iA22 = lk_wave_sum(sA22);
+        const float A11 = __ll2float_rn(iA11 * cn) * FLT_SCALE, A12 = __ll2float_rn(iA12 * cn) * FLT_SCALE,
+                    A22 = __ll2float_rn(iA22 * cn) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
+        if (minEig < a.min_eig || D < 1.1920928955078125e-07F) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.f / D;
+        const uint8_t* Jb = tk_px(pyrJ, L) + off;
+        float nx = np.x - half_x, ny = np.y - half_y;
+        float pdx = 0.f, pdy = 0.f;
+        for (int it = 0; it < a.max_count; it++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -ww || inx >= L.w || iny < -wh || iny >= L.h) {
+                if (level == 0) ok = false;
+                break;
+            }
+            fa = nx - inx;
+            fb = ny - iny;
+            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+            iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            const uint8_t* J0 = Jb + (ptrdiff_t)iny * pitch + inx;
+            const uint2 s0 = lk_load8(J0), s1 = lk_load8(J0 + pitch);
+            int sb1 = 0, sb2 = 0;  // per lane: NP terms below 2^26
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const int diff = TK_DESCALE(__mul24(lk_byte(s0, j), iw00) + __mul24(lk_byte(s0, j + 1), iw01) +
+                                                __mul24(lk_byte(s1, j), iw10) + __mul24(lk_byte(s1, j + 1), iw11),
+                                            W_BITS - 5) -
+                                 Iw[j];
+                sb1 += __mul24(diff, Dx[j]);
+                sb2 += __mul24(diff, Dy[j]);
+            }
+            const long long ib1 = lk_wave_sum(sb1), ib2 = lk_wave_sum(sb2);
+            const float b1 = __ll2float_rn(ib1 * cn) * FLT_SCALE, b2 = __ll2float_rn(ib2 * cn) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx;
+            ny += dy;
+            np = make_float2(nx + half_x, ny + half_y);
+            if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
+            if (it > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                np.x -= dx * 0.5f;
+                np.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+    }
+    if (lane == 0) {
+        next_pts[pt] = np;
+        status[pt] = ok ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
 void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr) {
@@ -424,6 +578,13 @@ void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, co
                      const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
                      const LkArgs& a) {
     if (n <= 0) return;
+    // a.generic (VO_OPT_LK_GENERIC): the 21 x 21 window through the kernels every other window size uses -- the
+    // parity tests compare the two
+    if (a.win_w == 21 && a.win_h == 21 && !a.generic) {
+        hipLaunchKernelGGL(k_lk_track_21, dim3(cdiv(n, 4)), dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts,
+                           status, n, a);
+        return;
+    }
     if (a.win_w * a.win_h <= 64 * LK_K) {
         hipLaunchKernelGGL(k_lk_track_small, dim3(cdiv(n, 4)), dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts,
                            next_pts, status, n, a);

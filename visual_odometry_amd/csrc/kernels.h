@@ -153,6 +153,7 @@ struct LkArgs {
     int win_w, win_h;
     int max_count;
     int channels;
+    int generic;  // 1: never the kernel specialised for the 21 x 21 window
     float min_eig;
     double eps2;
 };

@@ -174,6 +174,7 @@ int vo_ctx_create(int device, const vo_limits* limits, vo_ctx** out) {
     c->opt_seq_prefetch = env_int("VO_SEQ_PREFETCH", 0) != 0;
     c->opt_akaze_graph = env_int("VO_AKAZE_GRAPH", 1) != 0;
     c->opt_solver = env_int("VO_SOLVER", 0) != 0;
+    c->opt_lk_generic = env_int("VO_LK_GENERIC", 0) != 0;
     c->opt_knn_splits = std::max(0, env_int("VO_KNN_SPLITS", 0));
     if (c->lim.max_points > 65535 || c->lim.max_features > 262143 || c->lim.max_points < 5 ||
         c->lim.max_batch < 2 || c->lim.max_width < 7 || c->lim.max_height < 7) {
@@ -243,7 +244,7 @@ int vo_ctx_set_option(vo_ctx* c, int option, int value) {
     }
     int* sw = option == VO_OPT_KNN_MFMA ? &c->opt_knn_mfma : option == VO_OPT_ORB_SPLIT ? &c->opt_orb_split
               : option == VO_OPT_SEQ_PREFETCH ? &c->opt_seq_prefetch : option == VO_OPT_AKAZE_GRAPH ? &c->opt_akaze_graph
-              : option == VO_OPT_SOLVER ? &c->opt_solver : nullptr;
+              : option == VO_OPT_SOLVER ? &c->opt_solver : option == VO_OPT_LK_GENERIC ? &c->opt_lk_generic : nullptr;
     if (sw) {
         if (value != 0 && value != 1) return c->fail(VO_ERR_INVALID, "option %d takes 0 or 1", option);
         *sw = value;
@@ -268,6 +269,7 @@ int vo_ctx_get_option(vo_ctx* c, int option, int* value) {
     else if (option == VO_OPT_AKAZE_GRAPH) *value = c->opt_akaze_graph;
     else if (option == VO_OPT_SOLVER) *value = c->opt_solver;
     else if (option == VO_OPT_KNN_SPLITS) *value = c->opt_knn_splits;
+    else if (option == VO_OPT_LK_GENERIC) *value = c->opt_lk_generic;
     else return c->fail(VO_ERR_INVALID, "unknown option %d", option);
     return VO_OK;
 }

@@ -137,7 +137,11 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
         // The first round is sized so that a 32-pair batch is one partly filled wave per SIMD (one
         // solve latency; 128 per pair measured 30 % slower); every further round costs three launches
         // even when it exits at once, so the rounds grow by 4x: 64, 256, 680 for cv's 1000.
-        int h0 = 0, size = 64;
+        // A call for one or two pairs is a latency measurement, not a throughput one (BASELINE configs[1]): the chip
+        // is idle, 1 000 hypotheses solve and score in the time 64 do, and every extra round is three more dependent
+        // launches, so they all go out at once.  Which hypothesis wins does not depend on the rounds: k_replay applies
+        // cv's sequential rule to the counts in hypothesis order and ignores those past the (shrinking) cap.
+        int h0 = 0, size = npairs <= 2 ? std::min(H, 1024) : 64;
         while (h0 < H) {
             const int h1 = std::min(H, h0 + size);
             {

@@ -110,6 +110,7 @@ int vo_lk_track(vo_ctx* c, const uint8_t* prev, const uint8_t* next, int w, int 
         a.win_h = prm->win_h;
         a.max_count = std::min(std::max(prm->max_count, 0), 100);
         a.channels = prm->channels;
+        a.generic = c->opt_lk_generic;
         a.min_eig = (float)prm->min_eig_threshold;
         const double eps = std::min(std::max(prm->epsilon, 0.), 10.);
         a.eps2 = eps * eps;
