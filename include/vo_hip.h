@@ -80,6 +80,18 @@ void vo_lk_params_default(vo_lk_params* p);
 int vo_lk_track(vo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
                 const float* prev_pts, int n, const vo_lk_params* params, float* next_pts, uint8_t* status);
 
+/* vo_lk_track for n_seq independent image pairs of one size in ONE submission (no counterpart in the reference,
+ * which tracks one pair per call: src/features/feature_tracker.cpp:13).  The frames of one sequence are serial,
+ * sequences are not: a host that drives several sequences in lock step (visual_odometry_amd/host:
+ * vo_host_vo_run_concurrent) sends their frames through the tracker together, so that the pyramids, the
+ * derivative images and the point sets of all of them cost one upload, one launch each and one download.  Pair s
+ * = (prev[s], next[s]) with n[s] points; every result is bit-identical to vo_lk_track on that pair.  prev may be
+ * NULL (or hold NULLs for every pair): track from the `next` images of the previous call, which must have had
+ * the same geometry and n_seq.  At most 64 pairs a call. */
+int vo_lk_track_batch(vo_ctx* ctx, int n_seq, const uint8_t* const* prev, const uint8_t* const* next, int w, int h,
+                      int stride, const float* const* prev_pts, const int* n, const vo_lk_params* params,
+                      float* const* next_pts, uint8_t* const* status);
+
 /* ---- matcher: replaces the body of matcher() (src/matcher/matcher.cpp) ------------------- */
 
 /* matcher->knnMatch(desc_q, desc_t, matches, 2) with "BruteForce-Hamming"
@@ -148,6 +160,17 @@ int vo_recover_pose(vo_ctx* ctx, const double* E, const float* p0, const float* 
 int vo_essential_pose(vo_ctx* ctx, const float* p0, const float* p1, int n, const double* K, int method,
                       double prob, double threshold, uint64_t seed, int max_iters, double dist_thresh, double* E,
                       uint8_t* mask, double* R, double* t, double* pts4d, int* n_good);
+
+/* vo_essential_pose for n_seq independent point sets in ONE submission (no counterpart in the reference; the
+ * companion of vo_lk_track_batch for a host that drives several sequences in lock step).  Set s: p0[s], p1[s] with
+ * n[s] points.  Outputs per set: E + 9 s, R + 9 s, t + 3 s, status[s] (VO_OK, or VO_ERR_FAILED where cv returns an
+ * empty matrix: then E and mask are zero, R and t untouched, n_good 0), mask[s] (n[s] bytes), pts4d[s] (4 x n[s]),
+ * n_good[s]; mask, pts4d, n_good and their entries may be NULL.  Every set's results are bit-identical to
+ * vo_essential_pose on that set.  At most 64 sets a call. */
+int vo_essential_pose_batch(vo_ctx* ctx, int n_seq, const float* const* p0, const float* const* p1, const int* n,
+                            const double* K, int method, double prob, double threshold, uint64_t seed, int max_iters,
+                            double dist_thresh, double* E, uint8_t* const* mask, double* R, double* t,
+                            double* const* pts4d, int* n_good, int* status);
 
 /* cv::AKAZE::create()->detectAndCompute(image, noArray(), keypoints, descriptors)
  * reference: FeatureDetector::detectComputeAKAZE, src/features/feature_detector.cpp:7,43-45, called by

@@ -249,3 +249,24 @@ def test_essential_pose_equals_the_two_calls(vo, method):
             assert np.array_equal(mp, m2) and np.array_equal(pts, pts2)
     rc2, E2, ng2, R2, t2, m2, pts2 = vo.essential_pose(p0[:3], p1[:3], K, method=meth)
     assert rc2 != 0 and ng2 == 0 and not E2.any() and not m2.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["lmeds", "ransac"])
+def test_essential_pose_batch_equals_single_calls(vo, method):
+    """vo_essential_pose_batch: S point sets in one submission give, set for set, the bits of vo_essential_pose -
+    sets of different sizes, one with fewer than five points (cv's empty-matrix case), one of pure noise."""
+    from visual_odometry_amd import api
+
+    m = api.LMEDS if method == "lmeds" else api.RANSAC
+    sets = []
+    for k, (n, ratio) in enumerate([(900, 0.8), (2500, 0.6), (3, 1.0), (400, 0.9), (64, 0.0), (5, 1.0), (1300, 0.7)]):
+        p0, p1, *_ = synth.correspondences(max(n, 8), seed=20 + k, inlier_ratio=ratio)
+        sets.append((p0[:n], p1[:n]))
+    want = [vo.essential_pose(a, b, K, method=m) for a, b in sets]
+    got = vo.essential_pose_batch([a for a, _ in sets], [b for _, b in sets], K, method=m)
+    assert want[2][0] == api.VO_ERR_FAILED and want[0][0] == 0 and want[1][0] == 0
+    for w, g in zip(want, got):
+        assert w[0] == g[0] and w[2] == g[2]
+        for i in (1, 3, 4, 5, 6):
+            assert np.array_equal(w[i], g[i]), i

@@ -128,3 +128,37 @@ def test_lk_track_rejects_bad_arguments(vo):
     with pytest.raises(api.VoError) as e:
         vo.lk_track(big, big, pts, api.lk_params())
     assert e.value.code == api.VO_ERR_CAPACITY
+
+
+def test_lk_track_batch_equals_single_calls(vo, oracle, frames):
+    """vo_lk_track_batch: S image pairs in one submission give, pair for pair, the bits of vo_lk_track - with point
+    sets of different sizes (one empty), and again with prev == None from the cached pyramids of the batch."""
+    from visual_odometry_amd import api
+
+    fr, _, _ = frames
+    prm = api.lk_params()
+    pairs = [(0, 1), (1, 2), (0, 2), (2, 1), (1, 0)]  # the fixture holds three frames
+    pts = []
+    for k, (a, _) in enumerate(pairs):
+        kp = vo.fast_detect(fr[a], 20, True)
+        p = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+        pts.append(p[: [len(p), 700, 0, 1, 2500][k]])
+    want = [vo.lk_track(fr[a], fr[b], p, prm) for (a, b), p in zip(pairs, pts)]
+    got_p, got_s = vo.lk_track_batch([fr[a] for a, _ in pairs], [fr[b] for _, b in pairs], pts, prm)
+    for (wp, ws), gp, gs in zip(want, got_p, got_s):
+        assert np.array_equal(wp, gp) and np.array_equal(ws, gs)
+    # chained: every sequence one frame further, from the pyramids the batch left
+    nxt = [(b + 1) % 3 for _, b in pairs]
+    pts2 = [gp[gs != 0] for gp, gs in zip(got_p, got_s)]
+    want2 = [vo.lk_track(fr[b], fr[c], p, prm) for (_, b), c, p in zip(pairs, nxt, pts2)]
+    vo.lk_track_batch([fr[a] for a, _ in pairs], [fr[b] for _, b in pairs], pts, prm)  # (the single calls used the cache)
+    got2_p, got2_s = vo.lk_track_batch(None, [fr[c] for c in nxt], pts2, prm)
+    for (wp, ws), gp, gs in zip(want2, got2_p, got2_s):
+        assert np.array_equal(wp, gp) and np.array_equal(ws, gs)
+    # the oracle itself on one pair of the batch
+    o1, os_ = oracle.lk_track(fr[1], fr[2], pts[1], oracle.lk_params())
+    assert np.array_equal(got_p[1], o1) and np.array_equal(got_s[1], os_)
+    with pytest.raises(api.VoError):  # a cached-pyramid call must bring the batch size of the call before
+        vo.lk_track_batch(None, [fr[1], fr[2]], pts[:2], prm)
+    with pytest.raises(api.VoError):  # at most 64 pairs a call
+        vo.lk_track_batch([fr[0]] * 65, [fr[1]] * 65, [pts[3]] * 65, prm)

@@ -122,6 +122,53 @@ class VoContext:
                                        _p(st)))
         return p1[:n].copy(), st[:n].copy()
 
+    def lk_track_batch(self, prevs, nexts, pts, params):
+        """S image pairs in one submission (vo_lk_track_batch).  prevs: list of images or None (track from the
+        previous call's `nexts`); pts: list of (n_s, 2) arrays.  Returns lists (next points, status)."""
+        S = len(nexts)
+        nexts = [_img(a) for a in nexts]
+        h, w = nexts[0].shape
+        stride = nexts[0].strides[0]
+        pv = None
+        if prevs is not None:
+            prevs = [_img(a) for a in prevs]
+            pv = (C.c_void_p * S)(*[a.ctypes.data for a in prevs])
+        nx = (C.c_void_p * S)(*[a.ctypes.data for a in nexts])
+        p0 = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 2) for p in pts]
+        n = (C.c_int * S)(*[len(p) for p in p0])
+        p1 = [np.zeros((max(len(p), 1), 2), np.float32) for p in p0]
+        st = [np.zeros(max(len(p), 1), np.uint8) for p in p0]
+        a0 = (C.c_void_p * S)(*[p.ctypes.data for p in p0])
+        a1 = (C.c_void_p * S)(*[p.ctypes.data for p in p1])
+        a2 = (C.c_void_p * S)(*[p.ctypes.data for p in st])
+        self._check(self.L.vo_lk_track_batch(self.h, S, pv, nx, w, h, stride, a0, n, C.byref(params), a1, a2))
+        return [p1[s][: len(p0[s])].copy() for s in range(S)], [st[s][: len(p0[s])].copy() for s in range(S)]
+
+    def essential_pose_batch(self, p0s, p1s, K, method=RANSAC, prob=0.999, threshold=1.0, seed=2**64 - 1,
+                             max_iters=1000, dist_thresh=200.0):
+        """vo_essential_pose_batch: list of per-set tuples (rc, E, n_good, R, t, mask, pts4d)."""
+        S = len(p0s)
+        p0 = [np.ascontiguousarray(p, np.float32).reshape(-1, 2) for p in p0s]
+        p1 = [np.ascontiguousarray(p, np.float32).reshape(-1, 2) for p in p1s]
+        K = np.ascontiguousarray(K, np.float64)
+        n = (C.c_int * S)(*[len(p) for p in p0])
+        E = np.zeros((S, 3, 3))
+        R = np.zeros((S, 3, 3))
+        t = np.zeros((S, 3))
+        mask = [np.zeros(max(len(p), 1), np.uint8) for p in p0]
+        pts = [np.zeros((4, max(len(p), 1))) if len(p) == 0 else np.zeros((4, len(p))) for p in p0]
+        ng = (C.c_int * S)()
+        stt = (C.c_int * S)()
+        a0 = (C.c_void_p * S)(*[p.ctypes.data for p in p0])
+        a1 = (C.c_void_p * S)(*[p.ctypes.data for p in p1])
+        am = (C.c_void_p * S)(*[p.ctypes.data for p in mask])
+        ap = (C.c_void_p * S)(*[p.ctypes.data for p in pts])
+        self._check(self.L.vo_essential_pose_batch(self.h, S, a0, a1, n, _p(K), int(method), C.c_double(prob),
+                                                   C.c_double(threshold), C.c_uint64(seed & (2**64 - 1)), int(max_iters),
+                                                   C.c_double(dist_thresh), _p(E), am, _p(R), _p(t), ap, ng, stt))
+        return [(stt[s], E[s].copy(), ng[s], R[s].copy(), t[s].copy(), mask[s][: len(p0[s])].copy(),
+                 pts[s][:, : len(p0[s])].copy()) for s in range(S)]
+
     def debug_read_lk_level(self, which, level):
         """which: 0 prev pyramid, 1 next pyramid, 2 derivative image (h x w x 2 int16)."""
         w, h = C.c_int(0), C.c_int(0)

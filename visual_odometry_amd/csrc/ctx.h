@@ -121,7 +121,9 @@ struct vo_ctx {
     DevBuf d_tk_deriv;   // short2 per pixel: Scharr derivatives of the `prev` pyramid, zero frame
     TrackGeom tk_geom;
     int tk_w = 0, tk_h = 0, tk_win_w = 0, tk_win_h = 0, tk_max_level = -1;
-    int tk_last = -1;    // slot of d_tk_pyr holding the pyramid of the last call's `next` image
+    int tk_last = -1;    // slot of d_tk_pyr holding the pyramids of the last call's `next` images
+    int tk_cap = 0;      // image pairs the tracker workspace holds side by side (vo_lk_track_batch)
+    int tk_last_count = 0;  // image pairs of the last call (a prev == NULL call must bring as many)
 
     // ---- AKAZE workspace (vo_akaze.cpp) ------------------------------------------------------
     DevBuf d_ak;       // float arena: work planes, then Lt / Lsmooth / Lx / Ly / Ldet of every level, AkContrast

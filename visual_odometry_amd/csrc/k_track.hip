@@ -40,8 +40,11 @@ __device__ __forceinline__ long long wave_sum(long long v) {
 }  // namespace
 
 // one thread per aligned dword of the padded level
-__global__ __launch_bounds__(256) void k_lk_level0(const uint8_t* __restrict__ img, int stride, TrackGeom g,
-                                                   uint8_t* __restrict__ pyr) {
+// blockIdx.z: image of a batch (images img_stride apart, pyramids g.bytes apart)
+__global__ __launch_bounds__(256) void k_lk_level0(const uint8_t* __restrict__ img, size_t img_stride, int stride,
+                                                   TrackGeom g, uint8_t* __restrict__ pyr) {
+    img += (size_t)blockIdx.z * img_stride;
+    pyr += (size_t)blockIdx.z * g.bytes;
     const TrackLevel L = g.lv[0];
     const int x4 = -TK_PAD + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = -TK_PAD + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -56,6 +59,7 @@ __global__ __launch_bounds__(256) void k_lk_level0(const uint8_t* __restrict__ i
 // The source level carries its reflect-101 frame, so source indices 2x-2 .. 2x+2 need no border
 // logic; frame pixels of the new level are the values at the reflected destination coordinate.
 __global__ __launch_bounds__(256) void k_lk_pyrdown(TrackGeom g, uint8_t* __restrict__ pyr, int level) {
+    pyr += (size_t)blockIdx.z * g.bytes;
     const TrackLevel D = g.lv[level], S = g.lv[level - 1];
     const int x4 = -TK_PAD + 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
     const int y = -TK_PAD + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -79,8 +83,13 @@ __global__ __launch_bounds__(256) void k_lk_pyrdown(TrackGeom g, uint8_t* __rest
 }
 
 // interior pixels only; reads the reflect-101 frame of the image for the edge rows / columns
+// blockIdx.z = image * nlevels + level: every level of every image in one launch (the grid covers level 0;
+// the blocks of a smaller level that lie outside it leave at once)
 __global__ __launch_bounds__(256) void k_lk_scharr(TrackGeom g, const uint8_t* __restrict__ pyr,
-                                                   short2* __restrict__ deriv, int level) {
+                                                   short2* __restrict__ deriv) {
+    const int im = blockIdx.z / g.nlevels, level = blockIdx.z - im * g.nlevels;
+    pyr += (size_t)im * g.bytes;
+    deriv += (size_t)im * g.bytes;
     const TrackLevel L = g.lv[level];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -100,11 +109,23 @@ __global__ __launch_bounds__(256) void k_lk_scharr(TrackGeom g, const uint8_t* _
 
 #define TK_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
+// The tracker kernels take a batch of point sets: blockIdx.y = image pair of the batch, whose pyramids and
+// derivative image lie g.bytes apart and whose points lie b.pts_stride apart; b.n[pair] points each.
+#define LK_BATCH_PROLOGUE                                          \
+    const int bi = blockIdx.y, n = b.n[bi];                        \
+    pyrI += (size_t)bi * g.bytes;                                  \
+    pyrJ += (size_t)bi * g.bytes;                                  \
+    deriv += (size_t)bi * g.bytes;                                 \
+    prev_pts += (size_t)bi * b.pts_stride;                         \
+    next_pts += (size_t)bi * b.pts_stride;                         \
+    status += (size_t)bi * b.pts_stride;
+
 __global__ __launch_bounds__(256) void k_lk_track(TrackGeom g, const uint8_t* __restrict__ pyrI,
                                                   const short2* __restrict__ deriv,
                                                   const uint8_t* __restrict__ pyrJ,
                                                   const float2* __restrict__ prev_pts, float2* __restrict__ next_pts,
-                                                  uint8_t* __restrict__ status, int n, LkArgs a) {
+                                                  uint8_t* __restrict__ status, LkBatch b, LkArgs a) {
+    LK_BATCH_PROLOGUE
     extern __shared__ int16_t lk_lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pt = blockIdx.x * 4 + wv;
@@ -255,7 +276,8 @@ __global__ __launch_bounds__(256) void k_lk_track_small(TrackGeom g, const uint8
                                                         const uint8_t* __restrict__ pyrJ,
                                                         const float2* __restrict__ prev_pts,
                                                         float2* __restrict__ next_pts, uint8_t* __restrict__ status,
-                                                        int n, LkArgs a) {
+                                                        LkBatch b, LkArgs a) {
+    LK_BATCH_PROLOGUE
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pt = blockIdx.x * 4 + wv;
     if (pt >= n) return;  // a whole wave leaves; the kernel has no block-wide barrier
@@ -421,7 +443,8 @@ __global__ __launch_bounds__(256) void k_lk_track_21(TrackGeom g, const uint8_t*
                                                      const uint8_t* __restrict__ pyrJ,
                                                      const float2* __restrict__ prev_pts,
                                                      float2* __restrict__ next_pts, uint8_t* __restrict__ status,
-                                                     int n, LkArgs a) {
+                                                     LkBatch b, LkArgs a) {
+    LK_BATCH_PROLOGUE
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pt = blockIdx.x * 4 + wv;
     if (pt >= n) return;  // a whole wave leaves; the kernel has no block-wide barrier
@@ -553,44 +576,44 @@ __global__ __launch_bounds__(256) void k_lk_track_21(TrackGeom g, const uint8_t*
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------
-void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr) {
+void launch_lk_pyramid(hipStream_t st, const uint8_t* img, size_t img_stride, int stride, const TrackGeom& g,
+                       uint8_t* pyr, int nimg) {
     {
         const TrackLevel& L = g.lv[0];
-        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4));
-        hipLaunchKernelGGL(k_lk_level0, grid, dim3(256), 0, st, img, stride, g, pyr);
+        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4), nimg);
+        hipLaunchKernelGGL(k_lk_level0, grid, dim3(256), 0, st, img, img_stride, stride, g, pyr);
     }
     for (int l = 1; l < g.nlevels; l++) {
         const TrackLevel& L = g.lv[l];
-        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4));
+        dim3 grid(cdiv(cdiv(L.w + 2 * TK_PAD, 4), 64), cdiv(L.h + 2 * TK_PAD, 4), nimg);
         hipLaunchKernelGGL(k_lk_pyrdown, grid, dim3(256), 0, st, g, pyr, l);
     }
 }
 
-void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv) {
-    for (int l = 0; l < g.nlevels; l++) {
-        const TrackLevel& L = g.lv[l];
-        dim3 grid(cdiv(L.w, 64), cdiv(L.h, 4));
-        hipLaunchKernelGGL(k_lk_scharr, grid, dim3(256), 0, st, g, pyr, deriv, l);
-    }
+void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv, int nimg) {
+    const TrackLevel& L = g.lv[0];
+    dim3 grid(cdiv(L.w, 64), cdiv(L.h, 4), nimg * g.nlevels);
+    hipLaunchKernelGGL(k_lk_scharr, grid, dim3(256), 0, st, g, pyr, deriv);
 }
 
 void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, const short2* deriv,
-                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
-                     const LkArgs& a) {
-    if (n <= 0) return;
+                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status,
+                     const LkBatch& b, const LkArgs& a) {
+    int nmax = 0;
+    for (int i = 0; i < b.count; i++) nmax = b.n[i] > nmax ? b.n[i] : nmax;
+    if (nmax <= 0 || b.count <= 0) return;
+    const dim3 grid(cdiv(nmax, 4), b.count);
     // a.generic (VO_OPT_LK_GENERIC): the 21 x 21 window through the kernels every other window size uses -- the
     // parity tests compare the two
     if (a.win_w == 21 && a.win_h == 21 && !a.generic) {
-        hipLaunchKernelGGL(k_lk_track_21, dim3(cdiv(n, 4)), dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts,
-                           status, n, a);
+        hipLaunchKernelGGL(k_lk_track_21, grid, dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts, status, b, a);
         return;
     }
     if (a.win_w * a.win_h <= 64 * LK_K) {
-        hipLaunchKernelGGL(k_lk_track_small, dim3(cdiv(n, 4)), dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts,
-                           next_pts, status, n, a);
+        hipLaunchKernelGGL(k_lk_track_small, grid, dim3(256), 0, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts, status,
+                           b, a);
         return;
     }
     const size_t lds = (size_t)4 * a.win_w * a.win_h * 3 * sizeof(int16_t);
-    hipLaunchKernelGGL(k_lk_track, dim3(cdiv(n, 4)), dim3(256), lds, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts,
-                       status, n, a);
+    hipLaunchKernelGGL(k_lk_track, grid, dim3(256), lds, st, g, pyrI, deriv, pyrJ, prev_pts, next_pts, status, b, a);
 }

@@ -157,11 +157,21 @@ struct LkArgs {
     float min_eig;
     double eps2;
 };
-void launch_lk_pyramid(hipStream_t st, const uint8_t* img, int stride, const TrackGeom& g, uint8_t* pyr);
-void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv);
+// A batch of tracking problems of one geometry (vo_lk_track_batch; a single call is a batch of one): image
+// pair i has n[i] points, stored pts_stride entries after those of pair i - 1.
+#define VO_LK_MAX_BATCH 64
+struct LkBatch {
+    int count;
+    int pts_stride;
+    int n[VO_LK_MAX_BATCH];
+};
+// nimg images img_stride bytes apart -> nimg pyramids g.bytes apart
+void launch_lk_pyramid(hipStream_t st, const uint8_t* img, size_t img_stride, int stride, const TrackGeom& g,
+                       uint8_t* pyr, int nimg);
+void launch_lk_scharr(hipStream_t st, const TrackGeom& g, const uint8_t* pyr, short2* deriv, int nimg);
 void launch_lk_track(hipStream_t st, const TrackGeom& g, const uint8_t* pyrI, const short2* deriv,
-                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status, int n,
-                     const LkArgs& a);
+                     const uint8_t* pyrJ, const float2* prev_pts, float2* next_pts, uint8_t* status,
+                     const LkBatch& b, const LkArgs& a);
 
 // ---- matcher ------------------------------------------------------------------------------
 // Packed neighbour key: distance << 22 | train index (numeric order == (distance, index) order).

@@ -308,6 +308,94 @@ int vo_essential_pose(vo_ctx* c, const float* p0, const float* p1, int n, const 
     return VO_OK;
 }
 
+// vo_essential_pose for n_seq independent point sets in one submission (the lock-step host of several sequences,
+// vo_host_vo_run_concurrent): the estimator and pose kernels already take a batch of pairs with per-pair counts
+// (the descriptor path runs them on 48 pairs at a time), so this is packing, one upload, the same launches with
+// npairs = n_seq, and one download per table.  Per-pair results are those of vo_essential_pose: a pair's kernels
+// only ever read that pair's rows, and the row stride does not enter any arithmetic.
+int vo_essential_pose_batch(vo_ctx* c, int n_seq, const float* const* p0, const float* const* p1, const int* n,
+                            const double* K, int method, double prob, double threshold, uint64_t seed, int max_iters,
+                            double dist_thresh, double* E, uint8_t* const* mask, double* R, double* t,
+                            double* const* pts4d, int* n_good, int* status) {
+    if (!c) return VO_ERR_INVALID;
+    if (n_seq < 1 || n_seq > 64 || !p0 || !p1 || !n || !K || !E || !R || !t || !status || !(prob > 0 && prob < 1) ||
+        (method != VO_RANSAC && method != VO_LMEDS) || max_iters < 1)
+        return c->fail(VO_ERR_INVALID, "vo_essential_pose_batch: bad argument (at most 64 point sets a call)");
+    int nmax = 0;
+    for (int s = 0; s < n_seq; s++) {
+        if (n[s] < 0 || (n[s] > 0 && (!p0[s] || !p1[s])))
+            return c->fail(VO_ERR_INVALID, "vo_essential_pose_batch: bad argument for point set %d", s);
+        nmax = std::max(nmax, n[s]);
+    }
+    VO_HIP(c, hipSetDevice(c->device));
+    for (int s = 0; s < n_seq; s++) {
+        for (int i = 0; i < 9; i++) E[9 * s + i] = 0;
+        if (mask && mask[s] && n[s] > 0) memset(mask[s], 0, n[s]);
+        if (n_good) n_good[s] = 0;
+        status[s] = VO_ERR_FAILED;
+    }
+    if (nmax < 5) return VO_OK;  // every set is cv's empty-matrix case
+    const int n_cap = (nmax + 63) & ~63;
+    const size_t np = (size_t)n_seq, tot = np * n_cap;
+    VO_TRY(vo_xfer_begin(c));
+    VO_TRY(geom_prepare(c, n_seq, n_cap, seed, max_iters));
+    VO_TRY(vo_ensure(c, c->d_fp0, tot * sizeof(float2)));
+    VO_TRY(vo_ensure(c, c->d_fp1, tot * sizeof(float2)));
+    VO_TRY(vo_ensure(c, c->d_ngood, (np + 1) * sizeof(int)));
+    // pinned staging: [p0 | p1 | counts] up, [EstState | PoseState | mask | pts4] down
+    const size_t up_bytes = 2 * tot * sizeof(float2) + np * sizeof(int);
+    const size_t dn_at = (up_bytes + 255) & ~(size_t)255;
+    const size_t st_bytes = np * sizeof(EstState), po_bytes = np * sizeof(PoseState);
+    const size_t mask_at = dn_at + ((st_bytes + po_bytes + 255) & ~(size_t)255);
+    const size_t pts_at = mask_at + ((tot + 255) & ~(size_t)255);
+    VO_TRY(vo_ensure_pinned(c, c->h_pts, pts_at + 4 * tot * sizeof(double)));
+    char* hp = c->h_pts.as<char>();
+    float2* h0 = reinterpret_cast<float2*>(hp);
+    float2* h1 = h0 + tot;
+    int* hn = reinterpret_cast<int*>(h1 + tot);
+    for (int s = 0; s < n_seq; s++) {
+        hn[s] = n[s];
+        if (n[s]) {
+            memcpy(h0 + (size_t)s * n_cap, p0[s], (size_t)n[s] * sizeof(float2));
+            memcpy(h1 + (size_t)s * n_cap, p1[s], (size_t)n[s] * sizeof(float2));
+        }
+    }
+    VO_HIP(c, hipMemcpyAsync(c->d_fp0.p, h0, tot * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->d_fp1.p, h1, tot * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->d_ngood.p, hn, np * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int* d_n = c->d_ngood.as<int>();
+    VO_TRY(geom_find_essential_dev(c, n_seq, n_cap, c->d_fp0.as<float2>(), c->d_fp1.as<float2>(), d_n, 0, K, method, prob,
+                                   threshold, max_iters));
+    const double* d_E = reinterpret_cast<const double*>(c->d_state.as<char>() + offsetof(EstState, E));
+    VO_TRY(geom_recover_pose_dev(c, n_seq, n_cap, d_E, sizeof(EstState) / sizeof(double), nullptr, nullptr, d_n, 0, K,
+                                 dist_thresh, true));
+    EstState* hs = reinterpret_cast<EstState*>(hp + dn_at);
+    PoseState* hq = reinterpret_cast<PoseState*>(hp + dn_at + st_bytes);
+    VO_HIP(c, hipMemcpyAsync(hs, c->d_state.p, st_bytes, hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(hq, c->d_pose.p, po_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (mask) VO_HIP(c, hipMemcpyAsync(hp + mask_at, c->d_pmask.p, tot, hipMemcpyDeviceToHost, c->stream));
+    if (pts4d)
+        VO_HIP(c, hipMemcpyAsync(hp + pts_at, c->d_pts4.p, 4 * tot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    VO_TRY(vo_xfer_finish(c));
+    const double* hx = reinterpret_cast<const double*>(hp + pts_at);
+    for (int s = 0; s < n_seq; s++) {
+        if (hs[s].status != VO_OK) {  // n < 5, or no model: E and mask stay zero, R and t untouched
+            if (pts4d && pts4d[s] && n[s] > 0) memset(pts4d[s], 0, (size_t)4 * n[s] * sizeof(double));
+            continue;
+        }
+        status[s] = VO_OK;
+        memcpy(E + 9 * s, hs[s].E, 9 * sizeof(double));
+        memcpy(R + 9 * s, hq[s].R, 9 * sizeof(double));
+        memcpy(t + 3 * s, hq[s].tt, 3 * sizeof(double));
+        if (n_good) n_good[s] = hq[s].n_good;
+        if (mask && mask[s]) memcpy(mask[s], hp + mask_at + (size_t)s * n_cap, n[s]);
+        if (pts4d && pts4d[s])
+            for (int k = 0; k < 4; k++)
+                memcpy(pts4d[s] + (size_t)k * n[s], hx + ((size_t)s * 4 + k) * n_cap, (size_t)n[s] * sizeof(double));
+    }
+    return VO_OK;
+}
+
 int vo_five_point(vo_ctx* c, const double* x1, const double* x2, int count, int variant, double* models,
                   int* nmodels) {
     if (!c) return VO_ERR_INVALID;
