@@ -258,7 +258,8 @@ def main():
     ap.add_argument("--no-configs4", action="store_true", help="N = 1: skip the 22-sequence configs[4] side run")
     ap.add_argument("--no-single-pair", action="store_true", help="skip the configs[1] single-pair latency measurement")
     ap.add_argument("--no-lk", action="store_true", help="skip the default (FAST -> LK -> LMedS) pipeline measurement")
-    ap.add_argument("--lk-sequences", type=int, default=8, help="independent sequences of the concurrent LK run")
+    ap.add_argument("--lk-sequences", type=int, default=32, help="independent sequences of the concurrent LK run")
+    ap.add_argument("--lk-groups", type=int, default=4, help="lock-step groups the concurrent LK drivers form")
     ap.add_argument("--workload", choices=["auto", "configs4"], default="auto",
                     help="auto: configs[3] on one GPU, configs[4] on several; configs4: the 22 sequences also at N = 1")
     ap.add_argument("--dry-run", action="store_true",
@@ -664,14 +665,20 @@ def main():
             stages = {k: round(v[1], 1) for k, v in host_api.timing_get().items()}
             host_api.timing_enable(False)
             S = max(1, args.lk_sequences)
-            wallS, timedS, _ = host_api.run_concurrent(K, [frames[:nlk]] * S, warmup=wu)
+            G = max(1, min(args.lk_groups, S))
+            wallT, timedT, _ = host_api.run_concurrent(K, [frames[:nlk]] * min(S, 8), warmup=wu)
+            wallS, timedS, _ = host_api.run_concurrent(K, [frames[:nlk]] * S, warmup=wu, lockstep=G)
             lk = {"frames_per_s": timed1 / wall1, "per_stage_us": stages,
-                  "concurrent": {"sequences": S, "frames_per_s": timedS / wallS,
-                                 "speedup_over_one_sequence": (timedS / wallS) / (timed1 / wall1)},
+                  "concurrent": {"sequences": S, "lockstep_groups": G, "frames_per_s": timedS / wallS,
+                                 "speedup_over_one_sequence": (timedS / wallS) / (timed1 / wall1),
+                                 "threads_only": {"sequences": min(S, 8), "frames_per_s": timedT / wallT}},
                   "frames_per_sequence": nlk, "warmup_frames": wu,
                   "note": "VisualOdometry::addImage of the host mirror (C++), 1241x376 frames in host memory, 3-channel "
-                          "LK sums as the reference's CPU build; `concurrent`: S drivers on S host threads, each with "
-                          "its own contexts / HIP streams (vo_host_vo_run_concurrent)"}
+                          "LK sums as the reference's CPU build.  `concurrent`: S drivers on S host threads "
+                          "(vo_host_vo_run_concurrent) in G lock-step groups: the drivers of a group meet at their two "
+                          "device calls per frame, which go down as ONE vo_lk_track_batch / vo_essential_pose_batch "
+                          "(bit-identical per driver: tests/test_gpu_driver_concurrent.py); `threads_only`: every "
+                          "driver makes its own calls on its own streams"}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

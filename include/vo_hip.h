@@ -92,6 +92,13 @@ int vo_lk_track_batch(vo_ctx* ctx, int n_seq, const uint8_t* const* prev, const 
                       int stride, const float* const* prev_pts, const int* n, const vo_lk_params* params,
                       float* const* next_pts, uint8_t* const* status);
 
+/* Page-locked host memory (hipHostMalloc) for callers that assemble a batch themselves: when the `next` (or `prev`)
+ * images of vo_lk_track_batch are tightly packed and lie one after the other in such a block, they are sent by DMA
+ * from where they are instead of being gathered into the context's staging buffer first.  NULL on failure.
+ * A device must be usable; the memory belongs to the process, not to a context. */
+void* vo_host_alloc_pinned(size_t bytes);
+void vo_host_free_pinned(void* p);
+
 /* ---- matcher: replaces the body of matcher() (src/matcher/matcher.cpp) ------------------- */
 
 /* matcher->knnMatch(desc_q, desc_t, matches, 2) with "BruteForce-Hamming"

@@ -13,6 +13,12 @@ for S in Ss:
         host_api.timing_enable(True)
     wall, timed, _ = host_api.run_concurrent(K, [frames] * S, warmup=40)
     line = "S=%2d  %7.0f frames/s  (%.1f us per frame of wall time)" % (S, timed / wall, wall / timed * 1e6)
+    if S > 1:
+        for G in (1, 2, 4):
+            if G > S:
+                continue
+            wall, timed, _ = host_api.run_concurrent(K, [frames] * S, warmup=40, lockstep=G)
+            line += "   lock step x%d: %6.0f f/s" % (G, timed / wall)
     if S == 1:
         line += "  " + " ".join("%s=%.0f" % (k.replace(" ", "_"), v[1]) for k, v in host_api.timing_get().items())
         host_api.timing_enable(False)

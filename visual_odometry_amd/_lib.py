@@ -19,7 +19,7 @@ SYMBOLS = [
     "vo_knn2_hamming", "vo_match_filter", "vo_knn2_hamming_cross", "vo_match_filter_cross", "vo_knn2_hamming_static", "vo_find_essential", "vo_recover_pose", "vo_triangulate", "vo_five_point", "vo_essential_pose", "vo_akaze_params_default", "vo_akaze_detect_compute", "vo_debug_akaze_level",
     "vo_projection_matrix", "vo_pair_params_default", "vo_pairs_run_dev", "vo_pairs_get_frame",
     "vo_pairs_get_matches", "vo_prof_enable", "vo_prof_get", "vo_ctx_set_option", "vo_ctx_get_option", "vo_debug_read_level",
-    "vo_lk_params_default", "vo_lk_track", "vo_lk_track_batch", "vo_essential_pose_batch", "vo_debug_read_lk_level",
+    "vo_lk_params_default", "vo_lk_track", "vo_lk_track_batch", "vo_essential_pose_batch", "vo_host_alloc_pinned", "vo_host_free_pinned", "vo_debug_read_lk_level",
     "vo_seq_create", "vo_seq_destroy", "vo_seq_last_error", "vo_seq_streams", "vo_seq_ctx", "vo_seq_run", "vo_seq_run_ex", "vo_seq_run_multi", "vo_seq_get_stats",
 ]
 

@@ -8,6 +8,7 @@
 #include <numeric>
 
 #include "feature_tracker.h"
+#include "host_batch.h"
 #include "host_internal.h"
 #include "utils.h"
 
@@ -42,9 +43,23 @@ float FeatureTracker::trackPoints(VOFrame* vo0, VOFrame* vo1) {
     static_assert(sizeof(vo::Point2f) == 8, "packed points");
     {
         StageScope ts(3);
-        check(ctx_, vo_lk_track(ctx_, cached ? nullptr : a.px.data(), b.px.data(), a.width, a.height, a.width,
-                                n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
-                                n ? status.data() : nullptr));
+        if (vo::BatchGroup* grp = vo::current_group()) {
+            // lock-step mode (vo_host_vo_run_concurrent): this call joins those of the group's other drivers in one
+            // vo_lk_track_batch on the group's context, which holds the pyramids; same results
+            const uint8_t* next_px = b.px.data();
+            if (uint8_t* slot = grp->image_slot(vo::current_slot(), b.width, b.height)) {  // this thread's share of the gather
+                memcpy(slot, next_px, b.px.size());
+                next_px = slot;
+            }
+            const int rc = grp->lk_track(vo::current_slot(), a.px.data(), cached, next_px, a.width, a.height,
+                                         n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
+                                         n ? status.data() : nullptr);
+            if (rc != VO_OK) throw vo::Error(rc, grp->last_error());
+        } else {
+            check(ctx_, vo_lk_track(ctx_, cached ? nullptr : a.px.data(), b.px.data(), a.width, a.height, a.width,
+                                    n ? &vo0->points[0].x : nullptr, n, &lk_, n ? &vo1->points[0].x : nullptr,
+                                    n ? status.data() : nullptr));
+        }
     }
     cached_id_ = b.id;
     // Remove bad points

@@ -5,12 +5,14 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "host_batch.h"
 #include "host_internal.h"
 #include "vo_pose.h"
 
 // ---- updatePose -----------------------------------------------------------------------------------
 int updatePose(const vo::Matd& K, VOFrame* last_frame, VOFrame* new_frame) {
-    vo_ctx* ctx = vo::default_ctx();
+    vo::BatchGroup* const grp = vo::current_group();  // lock-step mode of vo_host_vo_run_concurrent, else nullptr
+    vo_ctx* ctx = grp ? nullptr : vo::default_ctx();
     const int n = (int)new_frame->points.size();
     if ((int)last_frame->points.size() != n) throw vo::Error(VO_ERR_INVALID, "updatePose: point counts differ");
     static_assert(sizeof(vo::Point2f) == 8, "packed points");
@@ -28,9 +30,16 @@ int updatePose(const vo::Matd& K, VOFrame* last_frame, VOFrame* new_frame) {
     int rc;
     {
         StageScope ts(5);
-        rc = vo_essential_pose(ctx, p0, p1, n, K.d.data(), VO_LMEDS, 0.999, 1.0, ~(uint64_t)0, 1000, kMax3DDist,
-                               new_frame->E.d.data(), new_frame->mask.d.data(), new_frame->local_R.d.data(),
-                               new_frame->local_t.d.data(), points_4d.d.data(), &res);
+        if (grp) {  // one vo_essential_pose_batch for the whole group, on the group's context
+            rc = grp->essential_pose(vo::current_slot(), p0, p1, n, K.d.data(), VO_LMEDS, 0.999, 1.0, ~(uint64_t)0, 1000,
+                                     kMax3DDist, new_frame->E.d.data(), new_frame->mask.d.data(),
+                                     new_frame->local_R.d.data(), new_frame->local_t.d.data(), points_4d.d.data(), &res);
+            if (rc != VO_OK && rc != VO_ERR_FAILED) throw vo::Error(rc, grp->last_error());
+        } else {
+            rc = vo_essential_pose(ctx, p0, p1, n, K.d.data(), VO_LMEDS, 0.999, 1.0, ~(uint64_t)0, 1000, kMax3DDist,
+                                   new_frame->E.d.data(), new_frame->mask.d.data(), new_frame->local_R.d.data(),
+                                   new_frame->local_t.d.data(), points_4d.d.data(), &res);
+        }
     }
     if (rc == VO_OK) {
         StageScope ts(6);

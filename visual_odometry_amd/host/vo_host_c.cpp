@@ -10,7 +10,10 @@
 #include <string>
 #include <thread>
 
+#include <memory>
+
 #include "bundle_adjustment.h"
+#include "host_batch.h"
 #include "host_internal.h"
 #include "kitti.h"
 #include "matcher.h"
@@ -73,13 +76,25 @@ int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, doubl
 
 int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t scale_seed, int tracker_channels,
                               const uint8_t* const* frames, const int* n_frames, int n_seq, int w, int h, int warmup,
-                              double* const* poses, double* wall_seconds, long* timed_frames, char* err, int err_cap) {
+                              int lockstep, double* const* poses, double* wall_seconds, long* timed_frames, char* err,
+                              int err_cap) {
     if (!K || !frames || !n_frames || n_seq < 1 || n_seq > 64 || w <= 0 || h <= 0 || warmup < 0) {
         set_err(err, err_cap, "vo_host_vo_run_concurrent: bad argument");
         return -1;
     }
     vo::Matd Km(3, 3);
     for (int i = 0; i < 9; i++) Km.d[i] = K[i];
+    // lockstep = G > 0: G groups, driver s in group s mod G (slot s / G).  One group sends every driver's calls in one
+    // batch but leaves the GPU idle while the drivers do their host work; with two groups one's batch runs while the
+    // other's drivers are on the host.
+    const int G = std::max(0, std::min(lockstep, n_seq));
+    std::vector<std::unique_ptr<vo::BatchGroup>> groups;
+    try {
+        for (int g = 0; g < G; g++) groups.emplace_back(new vo::BatchGroup((n_seq - g + G - 1) / G));
+    } catch (const std::exception& e) {
+        set_err(err, err_cap, e.what());
+        return -1;
+    }
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0;
@@ -89,6 +104,9 @@ int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t 
     std::vector<clk::time_point> t_end((size_t)n_seq);
     long timed = 0;
     auto run = [&](int s) {
+        vo::BatchGroup* const group = G ? groups[(size_t)(s % G)].get() : nullptr;
+        const int slot = G ? s / G : -1;
+        vo::set_current_group(group, slot);  // (nullptr: every driver makes its own device calls)
         try {
             setScaleSeed(scale_seed + (uint32_t)s);  // this thread's generator
             VisualOdometry vo(Km, (size_t)min_tracked_points, false, tracker_channels);
@@ -116,7 +134,9 @@ int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t 
                 timed += n_frames[s] - nw;
             }
             for (int f = nw; f < n_frames[s]; f++) feed(f);
+            if (group) group->leave(slot);
         } catch (const std::exception& e) {
+            if (group) group->leave(slot);  // the others must not wait for a driver that has stopped
             std::lock_guard<std::mutex> lock(mu);
             if (first_error.empty()) first_error = e.what();
             if (arrived < n_seq) {  // never leave the others waiting at the barrier
@@ -125,6 +145,7 @@ int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t 
                 cv.notify_all();
             }
         }
+        vo::set_current_group(nullptr, -1);
         t_end[(size_t)s] = clk::now();
     };
     std::vector<std::thread> th;

@@ -31,10 +31,16 @@ int vo_host_vo_add_image(vo_host_vo* v, const uint8_t* gray, int w, int h, doubl
  * first `warmup` frames (context creation, sample table, buffer growth), then all meet at a barrier and the
  * rest is timed: *wall_seconds is the time until the last driver finishes, *timed_frames the frames inside it.
  * poses: NULL or n_seq pointers to n_frames[s] x 12 doubles.  Same results as n_seq separate drivers
- * (getScale's generator is per thread, seeded scale_seed + s).  Returns 0, or -1 with the message in err. */
+ * (getScale's generator is per thread, seeded scale_seed + s).
+ * lockstep = G > 0 (G groups, driver s in group s mod G; two let one group's batch run on the GPU while the other
+ * group's drivers do their host work): the drivers' two device calls per frame (tracker; findEssentialMat + recoverPose) meet in ONE
+ * vo_lk_track_batch / vo_essential_pose_batch call on a context of the group's own instead of S calls on S streams
+ * (host_batch.h); per-driver results stay bit-identical, the host parts of a frame still run on the S threads.
+ * Returns 0, or -1 with the message in err. */
 int vo_host_vo_run_concurrent(const double* K, int min_tracked_points, uint32_t scale_seed, int tracker_channels,
                               const uint8_t* const* frames, const int* n_frames, int n_seq, int w, int h, int warmup,
-                              double* const* poses, double* wall_seconds, long* timed_frames, char* err, int err_cap);
+                              int lockstep, double* const* poses, double* wall_seconds, long* timed_frames, char* err,
+                              int err_cap);
 
 /* Wall time per stage of the per-frame driver (what VO_HOST_TIMING=1 prints at exit), readable by a harness.
  * One set of counters per process, not synchronised: meaningful for a single driver thread only.

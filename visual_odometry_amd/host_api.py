@@ -46,8 +46,8 @@ def lib():
         _lib.vo_host_ba_match_matrix.argtypes = [C.c_void_p, C.c_void_p]
         _lib.vo_host_ba_points.argtypes = [C.c_void_p] * 4
         _lib.vo_host_vo_run_concurrent.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
-                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_char_p, C.c_int]
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         _lib.vo_host_timing_enable.argtypes = [C.c_int]
         _lib.vo_host_timing_enable.restype = None
         _lib.vo_host_timing_reset.restype = None
@@ -112,9 +112,10 @@ class HostVisualOdometry:
 
 
 def run_concurrent(K, sequences, min_tracked_points=750, scale_seed=1234, tracker_channels=3, warmup=0,
-                   want_poses=False):
+                   want_poses=False, lockstep=False):
     """S VisualOdometry drivers side by side, one host thread each (vo_host_vo_run_concurrent).  sequences: list
-    of (n, h, w) uint8 arrays of one frame size.  Returns (wall seconds of the timed part, frames in it, poses or
+    of (n, h, w) uint8 arrays of one frame size.  lockstep = G: the drivers form G groups whose device calls go down as
+    one batch per frame step (host_batch.h), same results.  Returns (wall seconds of the timed part, frames in it, poses or
     None)."""
     L = lib()
     K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
@@ -129,7 +130,7 @@ def run_concurrent(K, sequences, min_tracked_points=750, scale_seed=1234, tracke
     wall, timed = C.c_double(0), C.c_long(0)
     err = C.create_string_buffer(512)
     rc = L.vo_host_vo_run_concurrent(_p(K), int(min_tracked_points), int(scale_seed), int(tracker_channels), ptrs, counts,
-                                     n, w, h, int(warmup), pp, C.byref(wall), C.byref(timed), err, 512)
+                                     n, w, h, int(warmup), int(lockstep), pp, C.byref(wall), C.byref(timed), err, 512)
     if rc != 0:
         raise RuntimeError("run_concurrent: " + err.value.decode())
     return wall.value, timed.value, poses
