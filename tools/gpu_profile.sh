@@ -9,7 +9,7 @@ TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp VO_SYNTH_CACHE=/tmp/vo_synth_cache VO_SYNTH_NOFORK=0
-ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie --no-default-queues"
+ARGS="--streams 1 --frames 49 --base-frames 49 --no-cpu-baseline --no-8k --no-pcie --no-default-queues --no-configs4 --no-single-pair --no-lk"
 echo "[profile] render"; date +%T > $OUT/progress.txt
 timeout -k 10 240 python3 bench.py $ARGS --steps 1 --warmup 0 > $OUT/render.log 2>&1
 export VO_SYNTH_NOFORK=1

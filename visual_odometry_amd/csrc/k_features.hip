@@ -896,12 +896,83 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
     return ret;
 }
 
+// The rounds of nth_element on a range of at most 64 elements, by ONE wave with the elements in registers (lane p
+// holds position base + p): no block barrier and no LDS round trip per step.  A round of the block version costs
+// ~1 us whatever the range (three barriers, seven dependent LDS reads), and about half of a selection's rounds
+// run on ranges this small.  The same unguarded Hoare partition: with bL / bR the ballots of the stops of the
+// left / right pointer, the left stop at position p with k stops before it is swapped iff more than k right
+// stops lie behind it (the k-th swap exists iff a_k < b_k), partners are found through their common rank, and
+// the cut is min(a_K, b_{K-1}) as in block_partition<0>.  first, last, nth are relative to base; returns the
+// remaining depth budget, or -1 when libstdc++ would enter its heap-select fallback.
+__device__ __forceinline__ float wave_get(float v, int l) {  // v of lane l (wave-uniform l): v_readlane
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ int wave_nth_rounds(float& r, int& idx, int& first, int& last, int nth, int depth, int lane) {
+    const unsigned long long lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+    // wave-uniform by construction; said so, for the scalar unit
+    first = __builtin_amdgcn_readfirstlane(first);
+    last = __builtin_amdgcn_readfirstlane(last);
+    nth = __builtin_amdgcn_readfirstlane(nth);
+    depth = __builtin_amdgcn_readfirstlane(depth);
+    while (last - first > 3) {
+        if (depth == 0) return -1;
+        depth--;
+        const int mid = first + (last - first) / 2;
+        const float ra = wave_get(r, first + 1), rb = wave_get(r, mid), rc = wave_get(r, last - 1);
+        int sel;
+        float pivot;
+        if (ra > rb) {
+            if (rb > rc) sel = mid, pivot = rb;
+            else if (ra > rc) sel = last - 1, pivot = rc;
+            else sel = first + 1, pivot = ra;
+        } else if (ra > rc) sel = first + 1, pivot = ra;
+        else if (rb > rc) sel = last - 1, pivot = rc;
+        else sel = mid, pivot = rb;
+        {  // std::iter_swap(first, sel)
+            const float rf = wave_get(r, first), rs = wave_get(r, sel);
+            const int xf = __builtin_amdgcn_readlane(idx, first), xs = __builtin_amdgcn_readlane(idx, sel);
+            if (lane == first) r = rs, idx = xs;
+            else if (lane == sel) r = rf, idx = xf;
+        }
+        // __unguarded_partition(first + 1, last, pivot)
+        const bool in = lane > first && lane < last;
+        const bool isL = in && !(r > pivot);  // the left pointer stops: !comp(*first, pivot)
+        const bool isR = in && !(pivot > r);  // the right pointer stops: !comp(pivot, *last)
+        const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+        const int kL = __popcll(bL & lt), kR = __popcll(bR & gt);  // rank among the left stops / from the right
+        const int nLt = __popcll(bL);
+        const int K = __popcll(__ballot(isL && __popcll(bR & gt) > kL));
+        const bool swL = isL && kL < K, swR = isR && kR < K;
+        // partners meet in slot k (a lane index below 32: a swap takes two positions); the others aim at slot 63
+        const int to = swR ? kR : (swL ? kL : 63);
+        const float fromR_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(4 * (swR ? kR : 63), __builtin_bit_cast(int, r)));
+        const int fromR_x = __builtin_amdgcn_ds_permute(4 * (swR ? kR : 63), idx);
+        const float fromL_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(4 * (swL ? kL : 63), __builtin_bit_cast(int, r)));
+        const int fromL_x = __builtin_amdgcn_ds_permute(4 * (swL ? kL : 63), idx);
+        // slot k now holds the k-th right stop (fromR) and the k-th left stop (fromL); every swapping lane pulls its partner
+        const float getR_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * to, __builtin_bit_cast(int, fromR_r)));
+        const int getR_x = __builtin_amdgcn_ds_bpermute(4 * to, fromR_x);
+        const float getL_r = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * to, __builtin_bit_cast(int, fromL_r)));
+        const int getL_x = __builtin_amdgcn_ds_bpermute(4 * to, fromL_x);
+        if (swL) r = getR_r, idx = getR_x;
+        else if (swR) r = getL_r, idx = getL_x;
+        // cut = min(a_K, b_{K-1}) with `last` where the stop does not exist
+        const unsigned long long mA = __ballot(isL && kL == K), mB = __ballot(isR && kR == K - 1);
+        const int a = (K < nLt && mA) ? __ffsll((long long)mA) - 1 : last;
+        const int b = (K > 0 && mB) ? __ffsll((long long)mB) - 1 : last;
+        const int cut = min(a, b);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    return depth;
+}
+
 // std::nth_element(v + first, v + nth, v + last, greater-by-response); false when libstdc++ would
 // enter its heap-select fallback (depth limit reached).  Called by the whole block.
 __device__ bool block_nth_element(RI* v, int first, int nth, int last, uint16_t* Lp, uint16_t* Ra, int* sh, int tid) {
     if (first == last || nth == last) return true;
     int depth = 2 * (31 - __clz(last - first));
-    while (last - first > 3) {
+    while (last - first > 64) {
         if (depth == 0) return false;
         depth--;
         const int mid = first + (last - first) / 2;
@@ -919,6 +990,26 @@ __device__ bool block_nth_element(RI* v, int first, int nth, int last, uint16_t*
         const int cut = block_partition<0>(v, first + 1, last, pivot, Lp, Ra, sh, tid, sel, rf);
         if (cut <= nth) first = cut;
         else last = cut;
+    }
+    // the remaining rounds (ranges of at most 64) by the first wave alone, elements in registers
+    if (last - first > 3) {
+        if (tid < 64) {
+            const int base = first, cnt = last - first;
+            RI e = v[base + min(tid, cnt - 1)];
+            int f = 0, l = cnt;
+            const int left = wave_nth_rounds(e.r, e.idx, f, l, nth - base, depth, tid);
+            if (tid < cnt) v[base + tid] = e;
+            if (tid == 0) {
+                sh[0] = left < 0 ? -1 : base + f;
+                sh[1] = base + l;
+            }
+        }
+        __syncthreads();
+        const int nf = sh[0], nl = sh[1];
+        __syncthreads();  // (sh is reused by the next partition)
+        if (nf < 0) return false;
+        first = nf;
+        last = nl;
     }
     // std::__insertion_sort on the remaining <= 3 elements
     if (tid == 0) {
