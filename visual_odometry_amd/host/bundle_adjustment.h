@@ -16,6 +16,11 @@
 // descriptor the rest of the accelerated path uses).  A deviation, stated: the reference indexes its point list by CAMERA index where it means the list
 // position (:90: points[cam_idx]) — out of bounds whenever a track skips key frame 0; this mirror uses the
 // position, which is what the line computes whenever it is defined.
+// A second deviation, stated: the reference triangulates with cv::sfm::triangulatePoints (opencv_contrib's sfm
+// module, :100), which is neither vendored in the reference nor installed here; this mirror calls
+// triangulate() (triangulation.h -> vo_triangulate, the DLT of cv::triangulatePoints).  For TWO views both are
+// the homogeneous DLT of the same 4 x 4 system, so the points agree up to the solver's rounding, but nothing
+// here can check that: the BA front end's points are "parity unpinned" (DESIGN.md section 2).
 #ifndef VO_HOST_BUNDLE_ADJUSTMENT_H
 #define VO_HOST_BUNDLE_ADJUSTMENT_H
 
