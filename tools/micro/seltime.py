@@ -19,3 +19,19 @@ for l in range(8):
     r = [t[l * 8 + k] for k in range(8)]
     print("level %d n=%5d start+%6.1f us: " % (l, r[7], (r[0] - t[0]) / 100.0) +
           "  ".join("%s %5.1f" % (names[k], (r[k + 1] - r[k]) / 100.0) for k in range(5)) + "  total %.1f us" % ((r[5] - r[0]) / 100.0))
+
+ld = (C.c_ulonglong * 32)()
+_lib.lib().vo_debug_ld_times(ld)
+for l in range(8):
+    print("level %d list build: masks+count %5.2f  barrier %5.2f  scatter %5.2f  barrier %5.2f  scores %5.2f us" % (
+        l, (ld[l * 4] - t[l * 8]) / 100.0, (ld[l * 4 + 1] - ld[l * 4]) / 100.0, (ld[l * 4 + 2] - ld[l * 4 + 1]) / 100.0,
+        (ld[l * 4 + 3] - ld[l * 4 + 2]) / 100.0, (t[l * 8 + 1] - ld[l * 4 + 3]) / 100.0))
+r = (C.c_ulonglong * 512)()
+n = C.c_int(0)
+_lib.lib().vo_debug_sel_rounds(r, C.byref(n))
+prev = None
+tags = {1: "block round", 2: "wave rounds", 3: "insertion", 4: "partition", 5: "done"}
+for k in range(n.value):
+    tag, rng, t = r[k] >> 60, (r[k] >> 40) & 0xfffff, r[k] & 0xffffffffff
+    print("%-12s range %5d  +%5.2f us" % (tags.get(tag, "?"), rng, 0.0 if prev is None else (t - prev) / 100.0))
+    prev = t

@@ -63,7 +63,7 @@ struct vo_ctx {
     DevBuf d_segbase; // int [frame][segs_total]: candidate-list position of each segment's first keypoint
     DevBuf d_lvlofs;  // int [frame][VO_ORB_MAX_LEVELS + 1]
     DevBuf d_cand;    // Cand [frame][max_cand]: row-major candidates, level after level
-    DevBuf d_selcand; // Cand [frame][max_cand]: device selection, level l's picks (copies) at lvlofs[l]
+    DevBuf d_selcand; // Cand [frame][level][sel_cap]: device selection, the picks of every level (whole records)
     DevBuf d_selcnt;  // int [frame][VO_ORB_MAX_LEVELS]
     DevBuf d_flags;   // int [frame]: VO_SEL_* flags of the device selection
     DevBuf d_sel;     // Cand [frame][kp_cap]: selected keypoints in keypoint order (k_sel_flatten; rows of flagged frames from the host selection)
@@ -220,7 +220,7 @@ int vo_xfer_finish(vo_ctx* c);                                           // sync
 // features (vo_features.cpp)
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes);
 int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes, int fast_threshold,
-                int border, int nms);
+                int border, int nms, bool lists);  // lists: also the row-major candidate lists (plain FAST output)
 int feat_fetch_cands(vo_ctx* c, int nframes, const char* only = nullptr);  // only[f] != 0: fetch frame f
 int feat_select_dev(vo_ctx* c, int nframes, int n_bound);
 int feat_select_host(vo_ctx* c, int nframes, int* max_n_out);

@@ -289,7 +289,14 @@ struct FastTiles {  // first tile of every level, by value: the level of a block
 
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   uint8_t* __restrict__ score, unsigned long long* __restrict__ masks,
-                                                  int threshold, int border, int nms, FastTiles ft) {
+                                                  int threshold, int border, int nms, FastTiles ft,
+                                                  int* __restrict__ flags) {
+    // the per-frame selection flags of the batch start at zero (nframes + 1 entries; the detector is the first
+    // kernel of a batch that the selection follows)
+    if (flags && blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[blockIdx.y] = 0;
+        if (blockIdx.y == 0) flags[gridDim.y] = 0;
+    }
     __shared__ uint32_t px4[PX_H * (PX_W / 4)];
     // score map, rows PX_W apart like the pixel tile: pixel (sy, sx) of the score region is element
     // sy * PX_W + sx of the map and has its ring centred on element (sy + 3) * PX_W + sx + 3 of the tile
@@ -573,8 +580,9 @@ __global__ __launch_bounds__(1024) void k_row_scan(const PyrGeom* __restrict__ g
                                                    int* __restrict__ flags) {
     __shared__ int wtot[16];
     // the per-frame selection flags start at zero (this kernel runs once per batch before the selection)
-    if (threadIdx.x == 0) flags[blockIdx.x] = 0;
-    if (threadIdx.x == 1 && blockIdx.x == 0) flags[gridDim.x] = 0;
+    // (flags == NULL: the lists are made for the host redo of a batch whose flags must survive)
+    if (flags && threadIdx.x == 0) flags[blockIdx.x] = 0;
+    if (flags && threadIdx.x == 1 && blockIdx.x == 0) flags[gridDim.x] = 0;
     __shared__ int s_total;
     const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int total = g->segs_total, nlevels = g->nlevels;
@@ -808,7 +816,7 @@ struct RI {
 
 // MODE 0: std::__unguarded_partition(first, last, pivot) with comp(a, b) = a.r > b.r; returns cut.
 // MODE 1: std::__partition(first, last, pred) with pred(a) = a.r >= key; returns the new end.
-// All 256 threads call it with the same arguments.  Each wave lists the stops of its quarter of the
+// All threads of the block call it with the same arguments.  Each wave lists the stops of its quarter of the
 // range in its own segment of Lp / Ra; the j-th stop overall is found through the four segment counts
 // (sh[0..7]), so the lists are never compacted.
 // MODE 0 also carries nth_element's pivot move: the caller has chosen v[piv] as the pivot and wants it
@@ -818,31 +826,35 @@ struct RI {
 template <int MODE>
 __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* Lp, uint16_t* Ra, int* sh, int tid,
                                int piv = -1, float sub_r = 0.f) {
+    // the block has SEL_THREADS threads; the first 256 (four waves) share a round, the others keep step at the
+    // barriers: a round is a chain of LDS round trips and barriers whose length does not shrink with more waves
+    const bool worker = tid < 256;
     const int wv = tid >> 6, lane = tid & 63;
     const int span = ((last - first + 255) >> 8) << 6;
     const int wb = first + wv * span, we = min(last, wb + span);
     int nL = 0, nR = 0;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int i0 = wb; i0 < we; i0 += 64) {
-        const int i = i0 + lane;
-        const bool in = i < we;
-        float r = in ? v[i].r : 0.f;
-        if (MODE == 0 && i == piv) r = sub_r;
-        bool isL, isR;
-        if (MODE == 0) {
-            isL = in && !(r > key);   // the left pointer stops: !comp(*first, pivot)
-            isR = in && !(key > r);   // the right pointer stops: !comp(pivot, *last)
-        } else {
-            isR = in && (r >= key);   // the right pointer stops on pred
-            isL = in && !(r >= key);  // the left pointer stops on !pred
+    if (worker)
+        for (int i0 = wb; i0 < we; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = i < we;
+            float r = in ? v[i].r : 0.f;
+            if (MODE == 0 && i == piv) r = sub_r;
+            bool isL, isR;
+            if (MODE == 0) {
+                isL = in && !(r > key);   // the left pointer stops: !comp(*first, pivot)
+                isR = in && !(key > r);   // the right pointer stops: !comp(pivot, *last)
+            } else {
+                isR = in && (r >= key);   // the right pointer stops on pred
+                isL = in && !(r >= key);  // the left pointer stops on !pred
+            }
+            const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
+            if (isL) Lp[wb + nL + __popcll(bL & lt)] = (uint16_t)i;
+            if (isR) Ra[wb + nR + __popcll(bR & lt)] = (uint16_t)i;
+            nL += __popcll(bL);
+            nR += __popcll(bR);
         }
-        const unsigned long long bL = __ballot(isL), bR = __ballot(isR);
-        if (isL) Lp[wb + nL + __popcll(bL & lt)] = (uint16_t)i;
-        if (isR) Ra[wb + nR + __popcll(bR & lt)] = (uint16_t)i;
-        nL += __popcll(bL);
-        nR += __popcll(bR);
-    }
-    if (lane == 0) {
+    if (lane == 0 && worker) {
         sh[wv] = nL;
         sh[4 + wv] = nR;
     }
@@ -868,14 +880,15 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
     const int m = min(nLt, nRt);
     int Kw = 0;  // number of swaps: stops cross monotonically
     int a0 = 0, b0 = 0;  // the thread's first pair of stops, kept for the swap below
-    for (int k0 = 0; k0 < m; k0 += 256) {
-        const int k = k0 + tid;
-        const int a = k < m ? leftStop(k) : 0, b = k < m ? rightStop(k) : 0;
-        if (k0 == 0) a0 = a, b0 = b;
-        const bool ok = k < m && a < b;
-        Kw += __popcll(__ballot(ok));
-    }
-    if (lane == 0) sh[8 + wv] = Kw;
+    if (worker)
+        for (int k0 = 0; k0 < m; k0 += 256) {
+            const int k = k0 + tid;
+            const int a = k < m ? leftStop(k) : 0, b = k < m ? rightStop(k) : 0;
+            if (k0 == 0) a0 = a, b0 = b;
+            const bool ok = k < m && a < b;
+            Kw += __popcll(__ballot(ok));
+        }
+    if (lane == 0 && worker) sh[8 + wv] = Kw;
     __syncthreads();
     const int K = sh[8] + sh[9] + sh[10] + sh[11];
     int ret;
@@ -886,12 +899,13 @@ __device__ int block_partition(RI* v, int first, int last, float key, uint16_t* 
     } else {
         ret = first + nRt;
     }
-    for (int k = tid; k < K; k += 256) {
-        const int a = k == tid ? a0 : leftStop(k), b = k == tid ? b0 : rightStop(k);
-        const RI t = v[a];
-        v[a] = v[b];
-        v[b] = t;
-    }
+    if (worker)
+        for (int k = tid; k < K; k += 256) {
+            const int a = k == tid ? a0 : leftStop(k), b = k == tid ? b0 : rightStop(k);
+            const RI t = v[a];
+            v[a] = v[b];
+            v[b] = t;
+        }
     __syncthreads();
     return ret;
 }
@@ -998,20 +1012,41 @@ __device__ bool block_nth_element(RI* v, int first, int nth, int last, uint16_t*
             RI e = v[base + min(tid, cnt - 1)];
             int f = 0, l = cnt;
             const int left = wave_nth_rounds(e.r, e.idx, f, l, nth - base, depth, tid);
-            if (tid < cnt) v[base + tid] = e;
-            if (tid == 0) {
-                sh[0] = left < 0 ? -1 : base + f;
-                sh[1] = base + l;
+            // std::__insertion_sort on the remaining <= 3 elements [f, l), still in registers: a stable sort by
+            // descending response (an element moves in front of those it is strictly greater than)
+            if (left >= 0 && l - f >= 2) {
+                float r0 = wave_get(e.r, f), r1 = wave_get(e.r, f + 1), r2 = l - f == 3 ? wave_get(e.r, f + 2) : 0.f;
+                int x0 = __builtin_amdgcn_readlane(e.idx, f), x1 = __builtin_amdgcn_readlane(e.idx, f + 1),
+                    x2 = l - f == 3 ? __builtin_amdgcn_readlane(e.idx, f + 2) : 0;
+                if (r1 > r0) {
+                    const float tr = r0;
+                    const int tx = x0;
+                    r0 = r1, x0 = x1, r1 = tr, x1 = tx;
+                }
+                if (l - f == 3) {
+                    if (r2 > r0) {
+                        const float tr = r2;
+                        const int tx = x2;
+                        r2 = r1, x2 = x1, r1 = r0, x1 = x0, r0 = tr, x0 = tx;
+                    } else if (r2 > r1) {
+                        const float tr = r2;
+                        const int tx = x2;
+                        r2 = r1, x2 = x1, r1 = tr, x1 = tx;
+                    }
+                }
+                if (tid == f) e.r = r0, e.idx = x0;
+                if (tid == f + 1) e.r = r1, e.idx = x1;
+                if (l - f == 3 && tid == f + 2) e.r = r2, e.idx = x2;
             }
+            if (tid < cnt) v[base + tid] = e;
+            if (tid == 0) sh[0] = left;
         }
         __syncthreads();
-        const int nf = sh[0], nl = sh[1];
+        const int left = sh[0];
         __syncthreads();  // (sh is reused by the next partition)
-        if (nf < 0) return false;
-        first = nf;
-        last = nl;
+        return left >= 0;
     }
-    // std::__insertion_sort on the remaining <= 3 elements
+    // std::__insertion_sort on the remaining <= 3 elements (a block round went from more than 64 straight to here)
     if (tid == 0) {
         for (int i = first + 1; i < last; i++) {
             const RI val = v[i];
@@ -1043,48 +1078,144 @@ __device__ int block_retain_best(RI* v, int n, int n_points, uint16_t* Lp, uint1
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
-                                                    const int* __restrict__ lvlofs, Cand* __restrict__ cand,
-                                                    int max_cand, Quotas quota, int sel_cap,
-                                                    Cand* __restrict__ selcand, int* __restrict__ selcnt,
-                                                    int* __restrict__ flags) {
+// The list of a (frame, level) is built by its block straight from the detector's mask table — the words of a
+// level are its candidates in cv's order (row-major) —, so the device path needs neither the frame-wide prefix
+// scan nor the candidate lists in memory (k_row_scan + k_cand_write: two launches, 31 us of a 49-frame batch, and
+// an index -> candidate hop in front of every Harris patch); those two serve the plain FAST entry point and the host
+// redo of flagged frames.  A wave takes an eighth of the level's words in steps of 512 (a lane owns eight
+// consecutive words), counts, and after the block knows the eight totals writes position x | y << 16 of every set
+// bit at its rank; the FAST scores are then fetched by rank, eight loads in flight per thread.
+// SEL_THREADS threads: the list, the scores, the Harris responses and the output are work for every wave the CU
+// can hold (two blocks of 72 KB LDS and eight waves each); the partition rounds use the first four (see there).
+#define SEL_THREADS 512
+__global__ __launch_bounds__(SEL_THREADS) void k_orb_select(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
+                                                    const unsigned long long* __restrict__ masks,
+                                                    const uint8_t* __restrict__ score, int nms, Quotas quota,
+                                                    int sel_cap, Cand* __restrict__ selcand, int sel_fs,
+                                                    int* __restrict__ selcnt, int* __restrict__ flags) {
     extern __shared__ unsigned char sel_smem[];
     __shared__ int sh[12];
+    static_assert(SEL_THREADS / 64 <= 12, "sh holds one count per wave while the list is built");
     RI* v = reinterpret_cast<RI*>(sel_smem);
     uint16_t* Lp = reinterpret_cast<uint16_t*>(v + sel_cap);
     uint16_t* Ra = Lp + sel_cap;
     // grid (frames, levels): dispatch order is x fastest and round-robin over the 8 XCDs, so the long level-0
     // lists go out first and are spread over all XCDs (with the level in x every level-0 list sat on XCD 0)
     const int l = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
-    const int b = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l], max_cand);
-    const int e = min(lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + l + 1], max_cand);
-    int n = e - b;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int seg0 = g->lv[l].seg0, segs = g->lv[l].segs;
+    const int W = (l + 1 < g->nlevels ? g->lv[l + 1].seg0 : g->segs_total) - seg0;
+    const int rx0 = g->lv[l].rx0, ry0 = g->lv[l].ry0, pitch = g->lv[l].pitch;
     int* cnt = selcnt + (size_t)f * VO_ORB_MAX_LEVELS + l;
-    // a frame with more candidates than its list holds was truncated: the host path regrows the list
-    if (l == 0 && tid == 0 && lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + g->nlevels] > max_cand)
-        atomicOr(&flags[f], VO_SEL_OVERSIZE);
-    if (n > sel_cap) {
-        if (tid == 0) {
-            atomicOr(&flags[f], VO_SEL_OVERSIZE);
-            *cnt = 0;
+    const unsigned long long* M = masks + (size_t)f * g->segs_total + seg0;
+    constexpr int NW = SEL_THREADS / 64;
+    const int per = ((W + NW - 1) / NW + 511) & ~511;  // words per wave, whole steps of 512 (the table is padded)
+    const int beg = wv * per, end = min(W, beg + per);
+    int n;
+    // every load of the thread goes out before the first popcount: up to SB_STEPS steps of 512 words per wave stay
+    // in registers (a level of up to 8 192 words, 524 288 pixels of detector region); larger levels read twice
+    constexpr int SB_STEPS = 2;
+    const bool held = per <= SB_STEPS * 512;
+    unsigned long long mh[SB_STEPS][8];
+    {
+        int sum = 0;
+        if (held) {
+#pragma unroll
+            for (int s = 0; s < SB_STEPS; s++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) mh[s][u] = s * 512 < per ? M[beg + 512 * s + 8 * lane + u] : 0ull;
+#pragma unroll
+            for (int s = 0; s < SB_STEPS; s++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (beg + 512 * s + 8 * lane + u >= end) mh[s][u] = 0ull;
+                    sum += __popcll(mh[s][u]);
+                }
+        } else {
+            for (int i0 = beg; i0 < end; i0 += 512) {
+                unsigned long long m[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) m[u] = M[i0 + 8 * lane + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) sum += i0 + 8 * lane + u < end ? __popcll(m[u]) : 0;
+            }
         }
-        return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) sh[wv] = sum;
+        __syncthreads();
+        int run = 0;
+        for (int k = 0; k < wv; k++) run += sh[k];
+        n = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) n += sh[k];
+        if (n > sel_cap) {
+            if (tid == 0) {
+                atomicOr(&flags[f], VO_SEL_OVERSIZE);
+                *cnt = 0;
+            }
+            return;
+        }
+        // one step: the lane's eight words -> ranks by a wave scan -> x | y << 16 of every set bit at its rank
+        auto scatter = [&](const unsigned long long (&m)[8], int ib) {
+            int t = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) t += __popcll(m[u]);
+            int inc = t;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int q = __shfl_up(inc, o);
+                if (lane >= o) inc += q;
+            }
+            int pos = run + inc - t;
+            run += __shfl(inc, 63);
+            if (t == 0) return;
+            int yr = ib / segs, sx = ib - yr * segs;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                unsigned long long mm = m[u];
+                const uint32_t yx = (uint32_t)(ry0 + yr) << 16 | (uint32_t)(rx0 + sx * 64);
+                while (mm) {
+                    const int bit = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    v[pos].idx = (int)(yx + bit);
+                    pos++;
+                }
+                if (++sx == segs) sx = 0, yr++;
+            }
+        };
+        if (held) {
+#pragma unroll
+            for (int s = 0; s < SB_STEPS; s++)
+                if (beg + 512 * s < end) scatter(mh[s], beg + 512 * s + 8 * lane);
+        } else {
+            for (int i0 = beg; i0 < end; i0 += 512) {
+                unsigned long long m[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    m[u] = M[i0 + 8 * lane + u];  // second read: L2
+                    if (i0 + 8 * lane + u >= end) m[u] = 0;
+                }
+                scatter(m, i0 + 8 * lane);
+            }
+        }
     }
-    Cand* C = cand + (size_t)f * max_cand;
-    for (int i0 = 0; i0 < n; i0 += 1024) {  // four loads in flight per thread
-        int sc4[4];
+    __syncthreads();
+    {
+        const uint8_t* S = level_px(score, g, f, l);
+        for (int i0 = 0; i0 < n; i0 += 8 * SEL_THREADS) {  // eight loads in flight per thread
+            int sc8[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) sc4[u] = C[b + min(i0 + 256 * u + tid, n - 1)].score;
+            for (int u = 0; u < 8; u++) {
+                const uint32_t yx = (uint32_t)v[min(i0 + SEL_THREADS * u + tid, n - 1)].idx;
+                sc8[u] = S[(size_t)(yx >> 16) * pitch + (yx & 0xffff)];
+            }
 #pragma unroll
-        for (int u = 0; u < 4; u++) pin_loaded(sc4[u]);
+            for (int u = 0; u < 8; u++) pin_loaded(sc8[u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = i0 + 256 * u + tid;
-            if (i < n) {
-                RI t;
-                t.r = (float)sc4[u];
-                t.idx = b + i;
-                v[i] = t;
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + SEL_THREADS * u + tid;
+                if (i < n) v[i].r = nms ? (float)(sc8[u] - 1) : 0.f;
             }
         }
     }
@@ -1098,12 +1229,9 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         return;
     }
     const uint8_t* img = level_px(pyr, g, f, l);
-    const int pitch = g->lv[l].pitch;
-    for (int i = tid; i < n; i += 256) {
-        Cand* c = C + v[i].idx;
-        const float hr = harris_response(img, pitch, c->x, c->y);
-        c->harris = hr;
-        v[i].r = hr;
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint32_t yx = (uint32_t)v[i].idx;
+        v[i].r = harris_response(img, pitch, (int)(yx & 0xffff), (int)(yx >> 16));
     }
     __syncthreads();
     n = block_retain_best(v, n, quota.q[l], Lp, Ra, sh, tid);
@@ -1114,12 +1242,18 @@ __global__ __launch_bounds__(256) void k_orb_select(const uint8_t* __restrict__ 
         }
         return;
     }
-    // the picks are written out as copies, so that the next kernel reads a keypoint with one load
-    // instead of index -> candidate
-    for (int i = tid; i < n; i += 256) {
-        Cand cd = C[v[i].idx];
+    // the picks of level l go to selcand[f][l * sel_cap ...] as whole records, so that the next kernel reads a
+    // keypoint with one load
+    for (int i = tid; i < n; i += SEL_THREADS) {
+        const uint32_t yx = (uint32_t)v[i].idx;
+        Cand cd;
+        cd.x = (int16_t)(yx & 0xffff);
+        cd.y = (int16_t)(yx >> 16);
+        cd.level = (int16_t)l;
+        cd.score = 0;  // the FAST score has done its work
         cd.harris = v[i].r;
-        selcand[(size_t)f * max_cand + b + i] = cd;
+        cd.pad = 0;
+        selcand[(size_t)f * sel_fs + (size_t)l * sel_cap + i] = cd;
     }
     if (tid == 0) *cnt = n;
 }
@@ -1148,8 +1282,8 @@ __global__ void k_sel_count(const PyrGeom* __restrict__ g, const int* __restrict
 // counts first -- one dependent load less in front of its pixel loads.  One block per frame (+ one for the
 // sentinel count).
 __global__ __launch_bounds__(256) void k_sel_flatten(const PyrGeom* __restrict__ g, const int* __restrict__ selcnt,
-                                                     const int* __restrict__ lvlofs, const Cand* __restrict__ selcand,
-                                                     int max_cand, int* __restrict__ flags, int* __restrict__ nkp,
+                                                     int sel_cap, const Cand* __restrict__ selcand,
+                                                     int sel_fs, int* __restrict__ flags, int* __restrict__ nkp,
                                                      int n_bound, int nframes, Cand* __restrict__ flat, int kp_cap) {
     const int f = blockIdx.x;
     if (f == nframes) {
@@ -1161,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_sel_flatten(const PyrGeom* __restrict__
 #pragma unroll
     for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
         cnt[i] = i < nl ? selcnt[(size_t)f * VO_ORB_MAX_LEVELS + i] : 0;
-        ofs[i] = lvlofs[(size_t)f * (VO_ORB_MAX_LEVELS + 1) + i];
+        ofs[i] = i * sel_cap;
         n += cnt[i];
     }
     if (n > n_bound) {
@@ -1169,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_sel_flatten(const PyrGeom* __restrict__
         n = n_bound;
     }
     if (threadIdx.x == 0) nkp[f] = n;
-    const uint4* src = reinterpret_cast<const uint4*>(selcand + (size_t)f * max_cand);
+    const uint4* src = reinterpret_cast<const uint4*>(selcand + (size_t)f * sel_fs);
     uint4* dst = reinterpret_cast<uint4*>(flat + (size_t)f * kp_cap);
     static_assert(sizeof(Cand) == 16, "candidates are copied as 16-byte words");
     for (int k = threadIdx.x; k < n; k += 256) {
@@ -1270,8 +1404,8 @@ static __device__ __forceinline__ void xcd_frame_block(int& bx, int& f) {
 // keypoint copy is in flight, the row and mask loads go out together.
 __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ pyr, const PyrGeom* __restrict__ g,
                                                   const Cand* __restrict__ sel, const int* __restrict__ flags,
-                                                  int max_cand, const Cand* __restrict__ selcand,
-                                                  const int* __restrict__ selcnt, const int* __restrict__ lvlofs,
+                                                  int sel_fs, const Cand* __restrict__ selcand,
+                                                  const int* __restrict__ selcnt, int sel_cap,
                                                   const int* __restrict__ nkp, int kp_cap,
                                                   vo_keypoint* __restrict__ out) {
     int bx, f;
@@ -1279,15 +1413,11 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
     const int n = nkp[f];
     // the per-level counts and offsets travel with the keypoint count (uniform addresses, one batch of
     // scalar loads), before the early exit that only needs the count
-    int cnt[VO_ORB_MAX_LEVELS], ofs[VO_ORB_MAX_LEVELS];
+    int cnt[VO_ORB_MAX_LEVELS];
     {
         const int* sc = selcnt + (size_t)f * VO_ORB_MAX_LEVELS;
-        const int* lo = lvlofs + (size_t)f * (VO_ORB_MAX_LEVELS + 1);
 #pragma unroll
-        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) {
-            cnt[i] = sc[i];
-            ofs[i] = lo[i];
-        }
+        for (int i = 0; i < VO_ORB_MAX_LEVELS; i++) cnt[i] = sc[i];
     }
     if ((int)(bx * 8 + 2 * (threadIdx.x >> 6)) >= n) return;  // the whole wave
     const int k = min((int)(bx * 8 + (threadIdx.x >> 5)), n - 1);
@@ -1309,14 +1439,14 @@ __global__ __launch_bounds__(256) void k_ic_angle(const uint8_t* __restrict__ py
                 if (rem < cnt[i]) {
                     found = true;
                     l = i;
-                    base = ofs[i];
+                    base = i * sel_cap;
                 } else {
                     rem -= cnt[i];
                 }
             }
         if (!found) rem = 0;  // k < nkp = sum of the counts: not reached
         lg = l;
-        cd = selcand[(size_t)f * max_cand + base + rem];
+        cd = selcand[(size_t)f * sel_fs + base + rem];
     }
     const int pitch = g->lv[lg].pitch;
     const unsigned lofs = g->lv[lg].offset;
@@ -1832,13 +1962,17 @@ void launch_pyr_resize(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg,
 }
 
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
-                     unsigned long long* masks, int threshold, int border, int nms, int nframes) {
-    if (hg.tiles_total == 0) return;
+                     unsigned long long* masks, int threshold, int border, int nms, int nframes, int* flags) {
+    if (hg.tiles_total == 0) {
+        if (flags) (void)hipMemsetAsync(flags, 0, (size_t)(nframes + 1) * sizeof(int), st);
+        return;
+    }
     dim3 grid(hg.tiles_total, nframes);
     FastTiles ft = {};
     ft.nlevels = hg.nlevels;
     for (int i = 0; i < hg.nlevels; i++) ft.tile0[i] = hg.lv[i].tile0;
-    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms, ft);
+    hipLaunchKernelGGL(k_fast_nms, grid, dim3(256), 0, st, pyr, d_geom, score, masks, threshold, border, nms, ft,
+                       flags);
 }
 
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
@@ -1860,27 +1994,29 @@ void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, co
 }
 
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
-                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
-                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes, Cand* flat, int kp_cap) {
+                       const unsigned long long* masks, const uint8_t* score, int nms, const Quotas& quota,
+                       int sel_cap, Cand* selcand, int* selcnt, int* flags, int* nkp, int n_bound, int nframes,
+                       Cand* flat, int kp_cap) {
     const size_t lds = (size_t)sel_cap * (sizeof(RI) + 2 * sizeof(uint16_t));
+    const int sel_fs = hg.nlevels * sel_cap;  // selcand: [frame][level][sel_cap]
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_orb_select),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_orb_select, dim3(nframes, hg.nlevels), dim3(256), lds, st, pyr, d_geom, lvlofs, cand,
-                       max_cand, quota, sel_cap, selcand, selcnt, flags);
+    hipLaunchKernelGGL(k_orb_select, dim3(nframes, hg.nlevels), dim3(SEL_THREADS), lds, st, pyr, d_geom, masks, score, nms,
+                       quota, sel_cap, selcand, sel_fs, selcnt, flags);
     if (flat)
-        hipLaunchKernelGGL(k_sel_flatten, dim3(nframes + 1), dim3(256), 0, st, d_geom, selcnt, lvlofs, selcand,
-                           max_cand, flags, nkp, n_bound, nframes, flat, kp_cap);
+        hipLaunchKernelGGL(k_sel_flatten, dim3(nframes + 1), dim3(256), 0, st, d_geom, selcnt, sel_cap, selcand,
+                           sel_fs, flags, nkp, n_bound, nframes, flat, kp_cap);
     else
         hipLaunchKernelGGL(k_sel_count, dim3(cdiv(nframes + 1, 64)), dim3(64), 0, st, d_geom, selcnt, flags, nkp,
                            n_bound, nframes);
 }
 
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
-                     int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int sel_fs, const Cand* selcand, const int* selcnt, int sel_cap, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes) {
     if (max_n <= 0) return;
     dim3 grid(cdiv(max_n, 8), nframes);
-    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, flags, max_cand, selcand, selcnt, lvlofs,
+    hipLaunchKernelGGL(k_ic_angle, grid, dim3(256), 0, st, pyr, d_geom, sel, flags, sel_fs, selcand, selcnt, sel_cap,
                        nkp, kp_cap, out);
 }
 

@@ -115,18 +115,20 @@ void launch_orient_rbrief(hipStream_t st, const uint8_t* pyr, const uint8_t* blu
                           const Cand* flat, const int* nkp, int kp_cap, int max_n, vo_keypoint* out, uint8_t* desc,
                           int nframes);
 void launch_fast_nms(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const uint8_t* pyr, uint8_t* score,
-                     unsigned long long* masks, int threshold, int border, int nms, int nframes);
+                     unsigned long long* masks, int threshold, int border, int nms, int nframes, int* flags);
 void launch_row_scan(hipStream_t st, const PyrGeom* d_geom, const unsigned long long* masks, int* segbase,
                      int* lvlofs, int* flags, int nframes);
 void launch_cand_write(hipStream_t st, const PyrGeom* d_geom, const PyrGeom& hg, const unsigned long long* masks,
                        const int* segbase, const uint8_t* score, int nms, Cand* cand, int max_cand, int nframes);
 void launch_harris(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const int* lvlofs, Cand* cand,
                    int max_cand, int grid_cand, const int* only_flagged, int nframes);
+// selcand: [frame][level][sel_cap] (frame stride nlevels * sel_cap)
 void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg,
-                       const int* lvlofs, Cand* cand, int max_cand, const Quotas& quota, int sel_cap, Cand* selcand,
-                       int* selcnt, int* flags, int* nkp, int n_bound, int nframes, Cand* flat, int kp_cap);
+                       const unsigned long long* masks, const uint8_t* score, int nms, const Quotas& quota,
+                       int sel_cap, Cand* selcand, int* selcnt, int* flags, int* nkp, int n_bound, int nframes,
+                       Cand* flat, int kp_cap);
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
-                     int max_cand, const Cand* selcand, const int* selcnt, const int* lvlofs, const int* nkp, int kp_cap,
+                     int sel_fs, const Cand* selcand, const int* selcnt, int sel_cap, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes);
 void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
                    const Taps7& taps, int nlevels_used, int nframes);

@@ -230,7 +230,7 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     VO_TRY(vo_ensure(c, c->d_segbase, nf * c->geom.segs_total * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_lvlofs, nf * (VO_ORB_MAX_LEVELS + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
-    VO_TRY(vo_ensure(c, c->d_selcand, nf * c->max_cand * sizeof(Cand)));
+    VO_TRY(vo_ensure(c, c->d_selcand, nf * (size_t)std::max(c->geom.nlevels, 1) * c->sel_cap * sizeof(Cand)));
     VO_TRY(vo_ensure(c, c->d_selcnt, nf * VO_ORB_MAX_LEVELS * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_flags, (nf + 1) * sizeof(int)));
     VO_TRY(vo_ensure(c, c->d_sel, nf * kp_cap * sizeof(Cand)));
@@ -244,10 +244,23 @@ int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
     return VO_OK;
 }
 
-// Stage A (asynchronous): padded pyramid, fused FAST + NMS + border filter tiles, row-major
-// candidate lists.  d_img: nframes images in device memory.
+// The frame-wide prefix scan of the mask table and the row-major candidate lists: what the plain FAST entry
+// point returns and what the host selection of flagged frames starts from.  The device selection reads the mask
+// table itself.  zero_flags: false for the redo of a batch, whose selection flags must survive.
+static int feat_make_lists(vo_ctx* c, int nframes, bool zero_flags) {
+    const PyrGeom& g = c->geom;
+    const PyrGeom* dg = c->d_geom.as<PyrGeom>();
+    launch_row_scan(c->stream, dg, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(), c->d_lvlofs.as<int>(),
+                    zero_flags ? c->d_flags.as<int>() : nullptr, nframes);
+    launch_cand_write(c->stream, dg, g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
+                      c->d_score.as<uint8_t>(), c->cand_nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
+    return vo_check_launch(c, "candidate lists");
+}
+
+// Stage A (asynchronous): padded pyramid, fused FAST + NMS + border filter tiles -> mask table and score map;
+// lists: also the row-major candidate lists.  d_img: nframes images in device memory.
 int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes, int fast_threshold,
-                int border, int nms) {
+                int border, int nms, bool lists) {
     const PyrGeom& g = c->geom;
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
     hipStream_t st = c->stream;
@@ -261,13 +274,10 @@ int feat_detect(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride
     {
         ProfScope ps(c, VO_PROF_FAST);
         launch_fast_nms(st, dg, g, pyr, c->d_score.as<uint8_t>(), c->d_masks.as<unsigned long long>(),
-                        std::min(std::max(fast_threshold, 0), 255), border, nms, nframes);
+                        std::min(std::max(fast_threshold, 0), 255), border, nms, nframes, c->d_flags.as<int>());
     }
-    launch_row_scan(st, dg, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(), c->d_lvlofs.as<int>(),
-                    c->d_flags.as<int>(), nframes);
-    launch_cand_write(st, dg, g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
-                      c->d_score.as<uint8_t>(), nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
     c->cand_nms = nms;
+    if (lists) return feat_make_lists(c, nframes, true);
     return vo_check_launch(c, "feature detection");
 }
 
@@ -285,11 +295,10 @@ static int feat_cand_capacity(vo_ctx* c, int nframes, bool* grew = nullptr) {
     int most = 0;
     for (int f = 0; f < nframes; f++) most = std::max(most, lv[f * (VO_ORB_MAX_LEVELS + 1) + g.nlevels]);
     if (most <= c->max_cand) return VO_OK;
-    if (grew) *grew = true;  // the regrown selection buffer lost the device picks of every frame
+    if (grew) *grew = true;  // the regrown lists start without Harris responses: the caller redoes every frame
     const size_t nf = (size_t)c->feat_frames;
     c->max_cand = (most + 65535) & ~65535;
     VO_TRY(vo_ensure(c, c->d_cand, nf * c->max_cand * sizeof(Cand)));
-    VO_TRY(vo_ensure(c, c->d_selcand, nf * c->max_cand * sizeof(Cand)));
     launch_cand_write(st, c->d_geom.as<PyrGeom>(), g, c->d_masks.as<unsigned long long>(), c->d_segbase.as<int>(),
                       c->d_score.as<uint8_t>(), c->cand_nms, c->d_cand.as<Cand>(), c->max_cand, nframes);
     return vo_check_launch(c, "candidate lists");
@@ -320,10 +329,11 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     hipStream_t st = c->stream;
     Quotas q;
     for (int l = 0; l < VO_ORB_MAX_LEVELS; l++) q.q[l] = l < c->geom.nlevels ? c->quota[l] : 0;
-    // d_flags was zeroed by the row scan of this batch (feat_detect)
-    launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom, c->d_lvlofs.as<int>(),
-                      c->d_cand.as<Cand>(), c->max_cand, q, c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
-                      c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound, nframes, c->d_sel.as<Cand>(), c->kp_cap);
+    // d_flags was zeroed by the detector of this batch (feat_detect)
+    launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom,
+                      c->d_masks.as<unsigned long long>(), c->d_score.as<uint8_t>(), c->cand_nms, q, c->sel_cap,
+                      c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(), c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound,
+                      nframes, c->d_sel.as<Cand>(), c->kp_cap);
     return vo_check_launch(c, "keypoint selection");
 }
 
@@ -335,6 +345,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
 int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     const PyrGeom& g = c->geom;
     bool grew = false;
+    VO_TRY(feat_make_lists(c, nframes, false));     // the device selection worked from the mask table alone
     VO_TRY(feat_cand_capacity(c, nframes, &grew));  // before Harris: a regrown list starts without responses
     std::vector<char> redo(nframes);
     int* hflags = c->h_flags.as<int>();
@@ -419,9 +430,8 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     }
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
-                        c->d_flags.as<int>(), c->max_cand, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
-                        c->d_lvlofs.as<int>(), c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
-                        nframes);
+                        c->d_flags.as<int>(), g.nlevels * c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
+                        c->sel_cap, c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(), nframes);
     launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
                   c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
     return vo_check_launch(c, "feature description");
@@ -436,7 +446,7 @@ int feat_n_bound(const vo_ctx* c, int nfeatures) {
 // host selection when a flag was raised.  Synchronises once; h_nkp holds the counts.
 int feat_orb_frames(vo_ctx* c, const uint8_t* d_img, size_t frame_stride, int stride, int nframes,
                     const vo_orb_params* p, int* max_n_out) {
-    VO_TRY(feat_detect(c, d_img, frame_stride, stride, nframes, p->fast_threshold, p->edge_threshold, 1));
+    VO_TRY(feat_detect(c, d_img, frame_stride, stride, nframes, p->fast_threshold, p->edge_threshold, 1, false));
     const int n_bound = feat_n_bound(c, p->nfeatures);
     VO_TRY(feat_select_dev(c, nframes, n_bound));
     VO_TRY(feat_describe(c, nframes, n_bound, true, false));
@@ -476,7 +486,7 @@ int vo_fast_detect(vo_ctx* c, const uint8_t* gray, int w, int h, int stride, int
     if (w < 7 || h < 7) return VO_OK;  // cv: no pixel has a full ring
     VO_TRY(feat_setup(c, w, h, nullptr, 1));
     VO_TRY(upload_image(c, gray, w, h, stride));
-    VO_TRY(feat_detect(c, c->d_img.as<uint8_t>(), (size_t)w * h, w, 1, threshold, 0, nms != 0));
+    VO_TRY(feat_detect(c, c->d_img.as<uint8_t>(), (size_t)w * h, w, 1, threshold, 0, nms != 0, true));
     VO_TRY(feat_fetch_cands(c, 1));
     const int total = c->h_lvlofs.as<int>()[1];
     const Cand* cand = c->h_cand.as<Cand>();

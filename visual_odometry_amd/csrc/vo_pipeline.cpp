@@ -95,7 +95,7 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
     {
         ProfScope ps(c, VO_PROF_FEATURES);
         VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
-                           prm->orb.edge_threshold, 1));
+                           prm->orb.edge_threshold, 1, false));
         VO_TRY(feat_select_dev(c, n_frames, n_bound));
         VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
     }
