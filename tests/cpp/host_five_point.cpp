@@ -22,3 +22,10 @@ extern "C" void host_triangulate_point(const double* P0, const double* P1, const
                                        const double* x1, double* X) {
     triangulate_point(P0, P1, x0[0], x0[1], x1[0], x1[1], X);
 }
+
+// X: null vector for the cameras P0, P1; Xm: the one jacobi_svd's mirror derives for the same cameras with their
+// fourth columns negated (what k_pose_points uses for recoverPose's candidates [R | -t]).
+extern "C" void host_triangulate_point_mirror(const double* P0, const double* P1, const double* x0,
+                                              const double* x1, double* X, double* Xm) {
+    triangulate_point(P0, P1, x0[0], x0[1], x1[0], x1[1], X, Xm);
+}

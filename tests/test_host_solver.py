@@ -111,3 +111,45 @@ def test_device_decompose_and_triangulate_match_oracle(host, oracle):
         host.host_triangulate_point(_p(P0), _p(P1), _p(x0), _p(x1), _p(out))
         q = oracle.triangulate_points(P0, P1, x0[None], x1[None])[:, 0]
         assert np.abs(out - q).max() < 1e-12
+
+
+def test_mirrored_triangulation_is_bit_identical_to_a_second_decomposition(host):
+    """k_pose_points decomposes the DLT system of [R | t] once and takes the null vector for [R | -t] from
+    jacobi_svd's sign tracking (small_linalg.h).  The claim is bit-equality with a decomposition of its own,
+    because every step of the one-sided Jacobi iteration is odd or even in the sign of a column.  Checked on the
+    CPU build of the same header: recoverPose-like geometry (points in front of, behind and far from the
+    cameras, noisy matches, pure rotation) and plain random cameras, every double compared as its bit pattern
+    (value equality where the negated column is all zeros)."""
+    rng = np.random.default_rng(5)
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    checked = swapped = 0
+    for trial in range(4000):
+        if trial % 4 == 3:
+            P1 = rng.normal(0, 1, (3, 4))  # not a rigid camera at all
+        else:
+            R = synth.rotation(rng.normal(0, 0.05 if trial % 4 else 0.5, 3))
+            t = rng.normal(0, 1, 3)
+            t = t / np.linalg.norm(t) * (0.0 if trial % 97 == 0 else 1.0)
+            P1 = np.hstack([R, t[:, None]])
+        Xw = rng.uniform([-8, -3, -30], [8, 3, 60], 3)
+        a = Xw[:2] / Xw[2] + rng.normal(0, 2e-3, 2)
+        Y = P1 @ np.r_[Xw, 1]
+        b = Y[:2] / (Y[2] if abs(Y[2]) > 1e-9 else 1.0) + rng.normal(0, 2e-3, 2)
+        if trial % 11 == 0:
+            b = rng.uniform(-0.6, 0.6, 2)  # a wrong match
+        P1m = P1.copy()
+        P1m[:, 3] = -P1m[:, 3]
+        X, Xm, Xs = np.zeros(4), np.zeros(4), np.zeros(4)
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        host.host_triangulate_point_mirror(_p(np.ascontiguousarray(P0)), _p(np.ascontiguousarray(P1)), _p(a), _p(b),
+                                           _p(X), _p(Xm))
+        host.host_triangulate_point(_p(np.ascontiguousarray(P0)), _p(np.ascontiguousarray(P1m)), _p(a), _p(b), _p(Xs))
+        if trial % 4 != 3 and trial % 97 == 0:
+            # a translation of exact zeros has nothing to mirror: the two runs may differ in the SIGN of a zero
+            # (equal as numbers; no comparison of recoverPose tells -0 from 0)
+            assert np.array_equal(Xm, Xs), (trial, Xm, Xs)
+        else:
+            assert Xm.tobytes() == Xs.tobytes(), (trial, Xm, Xs)
+        checked += 1
+        swapped += bool(np.signbit(Xm[0]) != np.signbit(X[0]))  # the tracked sign of the row flipped on the way
+    assert checked == 4000 and 100 < swapped < 3900  # both outcomes of the sign tracking occur

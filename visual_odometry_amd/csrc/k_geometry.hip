@@ -514,32 +514,44 @@ __global__ __launch_bounds__(256) void k_pose_points(PoseState* __restrict__ ps,
     }
     const uint8_t min_ = (ok && mask_in) ? mask_in[(size_t)pair * n_cap + i] : 0xff;
     {
-        const int c = blockIdx.z;  // one of the four (R, t) candidates per block: 4x the waves, 1/4 the latency
-        bool m = false;
+        // blockIdx.z = 0, 1: the rotation R1 / R2.  Candidates c = z ([R | t]) and c = z + 2 ([R | -t]) share one
+        // decomposition: their DLT systems differ in the sign of the fourth column, and jacobi_svd's mirror gives
+        // the second null vector from the first with the bits four separate calls would produce (the oracle makes
+        // the four calls; tests/test_gpu_geometry.py holds the masks and points to it).
+        const int c = blockIdx.z;
+        bool m = false, mm = false;
         if (ok) {
-            double P1[12], X[4];
+            double P1[12], X[4], Xm[4];
 #pragma unroll
             for (int k = 0; k < 12; k++) P1[k] = s.P[c][k];
-            triangulate_point(P0, P1, u.x, u.y, v.x, v.y, X);
-            double* q = q4 + (((size_t)pair * 4 + c) * 4) * n_cap + i;
+            triangulate_point(P0, P1, u.x, u.y, v.x, v.y, X, Xm);
+            // candidate c, then candidate c + 2 with the translation column negated
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[(size_t)k * n_cap] = X[k];
-            m = X[2] * X[3] > 0;
-            const double xn = X[0] / X[3], yn = X[1] / X[3], zn = X[2] / X[3], wn = X[3] / X[3];
-            m = (zn < dist) && m;
-            double z2 = 0;
-            z2 += P1[8] * xn;
-            z2 += P1[9] * yn;
-            z2 += P1[10] * zn;
-            z2 += P1[11] * wn;
-            m = (z2 > 0) && m;
-            m = (z2 < dist) && m;
-            const uint8_t mv = (uint8_t)((m ? 255 : 0) & min_);
-            cmask[((size_t)pair * 4 + c) * n_cap + i] = mv;
-            m = mv != 0;
+            for (int h = 0; h < 2; h++) {
+                const double* Xh = h ? Xm : X;
+                const int ch = c + 2 * h;
+                double* q = q4 + (((size_t)pair * 4 + ch) * 4) * n_cap + i;
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[(size_t)k * n_cap] = Xh[k];
+                bool mh = Xh[2] * Xh[3] > 0;
+                const double xn = Xh[0] / Xh[3], yn = Xh[1] / Xh[3], zn = Xh[2] / Xh[3], wn = Xh[3] / Xh[3];
+                mh = (zn < dist) && mh;
+                double z2 = 0;
+                z2 += P1[8] * xn;
+                z2 += P1[9] * yn;
+                z2 += P1[10] * zn;
+                z2 += (h ? -P1[11] : P1[11]) * wn;
+                mh = (z2 > 0) && mh;
+                mh = (z2 < dist) && mh;
+                const uint8_t mv = (uint8_t)((mh ? 255 : 0) & min_);
+                cmask[((size_t)pair * 4 + ch) * n_cap + i] = mv;
+                if (h) mm = mv != 0;
+                else m = mv != 0;
+            }
         }
-        const int cnt = __popcll(__ballot(m));
+        const int cnt = __popcll(__ballot(m)), cntm = __popcll(__ballot(mm));
         if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s.good[c], cnt);
+        if ((threadIdx.x & 63) == 0 && cntm) atomicAdd(&s.good[c + 2], cntm);
     }
 }
 
@@ -685,7 +697,7 @@ void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps
                  double dist, double* q4, uint8_t* cmask, uint8_t* mask_out, double* pts4, int npairs) {
     hipLaunchKernelGGL(k_pose_setup, dim3(cdiv(npairs, 64)), dim3(64), 0, st, E, e_stride, ps, npairs);
     if (n_grid > 0)
-        hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs, 4), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
+        hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs, 2), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
                            n_cap, mask_in, dist, q4, cmask);
     hipLaunchKernelGGL(k_pose_select, dim3(npairs), dim3(256), 0, st, ps, d_n, n_host, n_cap, q4, cmask, mask_out,
                        pts4);

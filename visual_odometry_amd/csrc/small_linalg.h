@@ -17,8 +17,20 @@
 
 // In:  At[i][k] = A[k][i] (rows of At are the columns of A).
 // Out: W descending; At rows = columns of U (normalised); Vt rows = right singular vectors.
+//
+// mirror (optional, in / out): the decomposition of A with some columns NEGATED, for free.  Bit r of *mirror
+// says that column r (row r of At) is negated in the mirrored problem.  Every step of the algorithm is odd or even
+// in those signs — IEEE rounding is symmetric, so p = <a_i, a_j> of the mirrored problem is exactly +-p, beta and
+// gamma are the same, and of (c, s) exactly one changes sign when p does: s on the branch beta >= 0 (the rotated
+// rows keep their signs), c on the branch beta < 0 (the two rows EXCHANGE their signs) — hence the mirrored
+// run performs the same rotations on the same magnitudes and differs only in a sign per row, which is all that
+// needs tracking.  On return bit r says that row r of the mirrored Vt is the negative of D * Vt[r], D the diagonal
+// sign matrix of the negated columns: Vt'[r][k] = (bit r ? -1 : 1) * (column k negated ? -1 : 1) * Vt[r][k].
+// k_pose_points uses it for recoverPose's candidates [R | t] and [R | -t], whose DLT systems differ in the sign
+// of the fourth column: two decompositions per point instead of four, the same bits.
 template <int N>
-VO_HD void jacobi_svd(double (&At)[N][N], double (&W)[N], double (&Vt)[N][N]) {
+VO_HD void jacobi_svd(double (&At)[N][N], double (&W)[N], double (&Vt)[N][N], unsigned* mirror = nullptr) {
+    unsigned sg = mirror ? *mirror : 0u;
     const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -46,6 +58,7 @@ VO_HD void jacobi_svd(double (&At)[N][N], double (&W)[N], double (&Vt)[N][N]) {
                     const double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);
                     c = p / (gamma * s * 2);
+                    if (mirror && (((sg >> i) ^ (sg >> j)) & 1u)) sg ^= (1u << i) | (1u << j);  // the rows exchange signs
                 } else {
                     c = sqrt((gamma + beta) / (gamma * 2));
                     s = p / (gamma * c * 2);
@@ -97,6 +110,7 @@ VO_HD void jacobi_svd(double (&At)[N][N], double (&W)[N], double (&Vt)[N][N]) {
                 const double tw = W[i];
                 W[i] = W[k];
                 W[k] = tw;
+                if (mirror && (((sg >> i) ^ (sg >> k)) & 1u)) sg ^= (1u << i) | (1u << k);
 #pragma unroll
                 for (int q = 0; q < N; q++) {
                     double t = At[i][q];
@@ -152,6 +166,7 @@ VO_HD void jacobi_svd(double (&At)[N][N], double (&W)[N], double (&Vt)[N][N]) {
 #pragma unroll
         for (int k = 0; k < N; k++) At[i][k] *= s;
     }
+    if (mirror) *mirror = sg;
 }
 
 VO_HD double det3x3(const double* M) {
@@ -208,8 +223,10 @@ VO_HD void decompose_essential(const double* E, double* R1, double* R2, double* 
 }
 
 // One point of cv::triangulatePoints: null vector of the 4x4 DLT system, as row 3 of Vt.
+// Xm (optional): the null vector of the system with the fourth column of P0 and P1 negated, i.e. of the cameras
+// [R0 | -t0], [R1 | -t1], from the same decomposition (jacobi_svd's mirror).
 VO_HD void triangulate_point(const double* P0, const double* P1, double x0, double y0, double x1,
-                             double y1, double* X) {
+                             double y1, double* X, double* Xm = nullptr) {
     double At[4][4], W[4], Vt[4][4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -218,9 +235,15 @@ VO_HD void triangulate_point(const double* P0, const double* P1, double x0, doub
         At[k][2] = x1 * P1[8 + k] - P1[k];
         At[k][3] = y1 * P1[8 + k] - P1[4 + k];
     }
-    jacobi_svd<4>(At, W, Vt);
+    unsigned mirror = 1u << 3;
+    jacobi_svd<4>(At, W, Vt, Xm ? &mirror : nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) X[k] = Vt[3][k];
+    if (Xm) {
+        const bool neg = (mirror >> 3) & 1u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Xm[k] = (neg != (k == 3)) ? -Vt[3][k] : Vt[3][k];
+    }
 }
 
 #endif
