@@ -330,3 +330,31 @@ def test_orb_fused_orientation_description_equals_the_two_kernels(vo, oracle, fr
     assert np.array_equal(kf, ks) and np.array_equal(df, ds)
     ko, do = oracle.orb_detect_compute(img, oracle.orb_params(2000, edge_threshold=edge))
     assert np.array_equal(kf, ko) and np.array_equal(df, do)
+
+
+def test_orb_large_sparse_image_list_build_from_long_mask_tables(oracle):
+    """A 2600 x 1300 image with a few thousand isolated corners: the detector's mask table of a level has up to
+    ~50 000 words, far more than the 8 192 a selection block keeps in registers, so the block builds its list by the
+    two-pass loop (count, then read again and scatter) on levels 0-3 and from registers on the small levels; the
+    candidate counts stay below the selection buffer, so the device path is the one that runs (asserted)."""
+    from visual_odometry_amd import api
+
+    rng = np.random.default_rng(77)
+    h, w = 1300, 2600
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (60 + 40 * np.sin(xx / 300.0) + 30 * np.cos(yy / 170.0)).astype(np.float32)
+    for _ in range(900):
+        y, x = int(rng.integers(40, h - 80)), int(rng.integers(40, w - 80))
+        hh, ww = int(rng.integers(6, 40)), int(rng.integers(6, 40))
+        img[y:y + hh, x:x + ww] += float(rng.integers(50, 120)) * (1 if rng.random() < 0.5 else -1)
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    ko, do = oracle.orb_detect_compute(img, oracle.orb_params(2000))
+    assert len(ko) >= 1500
+    ctx = api.VoContext(0, max_width=w, max_height=h)
+    try:
+        ctx.set_option(api.OPT_SEL_CAP, 13000)
+        kg, dg = ctx.orb_detect_compute(img, api.orb_params(2000), cap=8000)
+        assert ctx.get_option(api.OPT_LAST_FLAGS) == 0
+        assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    finally:
+        ctx.close()
