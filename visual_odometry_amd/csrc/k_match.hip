@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_keys_to_dmatch(const uint2* keys, int n
     }
 }
 
-int knn_splits(int nq, int nt, int npairs, int dirs);  // vo_match.cpp
+int knn_splits(int nq, int nt, int npairs, int dirs, bool mfma);  // vo_match.cpp
 
 extern "C" int vo_knn2_hamming_static(vo_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt,
                                       int desc_bytes, vo_dmatch* d_out) {
@@ -667,7 +667,7 @@ extern "C" int vo_knn2_hamming_static(vo_ctx* c, const uint8_t* d_q, int nq, con
     a.nq = nq;
     a.nt = nt;
     a.words = desc_bytes / 4;
-    a.splits = knn_splits(nq, nt, 1, 1);
+    a.splits = knn_splits(nq, nt, 1, 1, desc_bytes == 32 && c->opt_knn_mfma);
     if (a.splits > KNN_STATIC_MAX_SPLITS) a.splits = KNN_STATIC_MAX_SPLITS;
     a.cross = 0;
     a.knn = ws;                         // [VO_KNN_STATIC_MAX] merged keys

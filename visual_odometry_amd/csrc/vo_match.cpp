@@ -8,12 +8,14 @@
 // Blocks of 64 queries x 4 waves; 1536 blocks put six waves on every SIMD of the chip, which is the
 // batched path's shape (48 pairs x 2000 queries) with no split at all.  A single small problem is cut
 // along the train range until the chip is about that full (every wave keeps >= 64 rows) and merged by
-// k_knn2_merge.
-int knn_splits(int nq, int nt, int npairs, int dirs) {
+// k_knn2_merge.  The matrix-core kernel (two waves per SIMD, a head of ~64 operand dwords per block) wants
+// fewer, longer blocks: about 512 and at most 8 splits (tools/knn_sweep.py: 8192 x 8192 26.7 -> 21.0 us,
+// 4096 13.9 -> 11.6, 2000 9.3 -> 8.8 against the popcount kernel's rule).
+int knn_splits(int nq, int nt, int npairs, int dirs, bool mfma) {
     const int blocks = cdiv(std::max(nq, 1), 64) * std::max(npairs, 1) * dirs;
-    int s = (1536 + blocks / 2) / blocks;
+    int s = ((mfma ? 512 : 1536) + blocks / 2) / blocks;
     s = std::min(s, std::max(nt, 1) / 256);
-    return std::max(1, std::min(s, 32));
+    return std::max(1, std::min(s, mfma ? 8 : 32));
 }
 
 int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q_stride, size_t t_stride,
@@ -30,7 +32,8 @@ int match_knn2_dev(vo_ctx* c, const uint32_t* d_q, const uint32_t* d_t, size_t q
     a.cross = cross ? 1 : 0;
     const int dirs = cross ? 2 : 1;
     const int env_s = c->opt_knn_splits;  // tuning hook for tools/bench_knn.py
-    a.splits = knn_splits(cross ? std::max(nq, nt) : nq, cross ? std::min(nq, nt) : nt, npairs, dirs);
+    a.splits = knn_splits(cross ? std::max(nq, nt) : nq, cross ? std::min(nq, nt) : nt, npairs, dirs,
+                          words == 8 && c->opt_knn_mfma);
     if (env_s) a.splits = std::max(1, std::min(env_s, std::max(nt, 1) / 64));
     a.nq_cap = nq_cap;
     a.npairs = npairs;
