@@ -369,6 +369,102 @@ __global__ __launch_bounds__(256) void k_lmeds_medians(const EstState* __restric
     }
 }
 
+// The same median by a whole block (four waves) per model, for calls with few pairs: there the launch is a
+// few hundred waves on a thousand SIMDs and lasts as long as ONE wave needs for its model (n fp64 Sampson errors,
+// four histogram passes over them); four waves share both.  Same selection, same value.
+__global__ __launch_bounds__(256) void k_lmeds_medians_blk(const EstState* __restrict__ st,
+                                                           const double2* __restrict__ x1,
+                                                           const double2* __restrict__ x2, int n_cap,
+                                                           const double* __restrict__ models,
+                                                           const int* __restrict__ nmodels,
+                                                           double* __restrict__ medians, int H) {
+    extern __shared__ uint32_t errs[];  // n_cap errors + 256 bins
+    __shared__ int s_below[4];
+    __shared__ uint32_t s_mx[4];
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = blockIdx.x / 10, m = blockIdx.x % 10;
+    const EstState& s = st[pair];
+    if (h >= s.niters) return;
+    const size_t slot = (size_t)pair * H + h;
+    if (m >= nmodels[slot]) return;
+    const int n = s.n;
+    const int ecap = (n_cap + 3) & ~3;
+    uint32_t* e = errs;
+    uint32_t* hist = e + ecap;  // 16-byte aligned
+    double E[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) E[k] = models[slot * 90 + 9 * m + k];
+    for (int i = tid; i < n; i += 256) {
+        const double2 u = x1[(size_t)pair * n_cap + i], v = x2[(size_t)pair * n_cap + i];
+        e[i] = __float_as_uint(sampson_error(E, u.x, u.y, v.x, v.y));
+    }
+    const int kb = n / 2;
+    // radix selection of rank kb: every thread ends with the value
+    uint32_t prefix = 0;
+    int k = kb;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();  // (also: the errors are written)
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t v = e[i];
+            if (shift == 24 || (v >> (shift + 8)) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint4 hq = reinterpret_cast<const uint4*>(hist)[lane];  // bins 4 lane .. 4 lane + 3, every wave
+        const int t = (int)(hq.x + hq.y + hq.z + hq.w);
+        int inc = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        const int owner = __ffsll((long long)__ballot(inc > k)) - 1;  // first lane whose bins reach rank k
+        const int ex = __shfl(inc - t, owner);
+        const uint32_t hx = __shfl(hq.x, owner), hy = __shfl(hq.y, owner), hz = __shfl(hq.z, owner);
+        int r = k - ex, b = 4 * owner;
+        if (r >= (int)hx) {
+            r -= hx, b++;
+            if (r >= (int)hy) {
+                r -= hy, b++;
+                if (r >= (int)hz) r -= hz, b++;
+            }
+        }
+        k = r;
+        prefix = (prefix << 8) | (uint32_t)b;
+        __syncthreads();  // the bins are read before they are cleared again
+    }
+    const uint32_t rb = prefix;
+    uint32_t ra = rb;
+    if (!(n & 1)) {
+        int below = 0;
+        uint32_t mx = 0;
+        for (int i = tid; i < n; i += 256) {
+            const uint32_t v = e[i];
+            if (v < rb) {
+                below++;
+                mx = max(mx, v);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            below += __shfl_xor(below, o);
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        if (lane == 0) {
+            s_below[wv] = below;
+            s_mx[wv] = mx;
+        }
+        __syncthreads();
+        below = s_below[0] + s_below[1] + s_below[2] + s_below[3];
+        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        if (below == kb) ra = mx;  // rank n/2 - 1 is the largest of the elements below
+    }
+    if (tid == 0) {
+        const float fa = __uint_as_float(ra), fb = __uint_as_float(rb);
+        medians[slot * 10 + m] = (n & 1) ? (double)fb : (double)(fa + fb) * 0.5;
+    }
+}
+
 // first strictly smaller median wins (hypotheses, then models, in order); sets the inlier threshold
 __global__ __launch_bounds__(64) void k_lmeds_select(EstState* __restrict__ st, const int* __restrict__ nmodels,
                                                      const double* __restrict__ medians, int H) {
@@ -678,12 +774,22 @@ void launch_replay(hipStream_t st, int h0, int h1, EstState* s, const int* nmode
 
 void launch_lmeds(hipStream_t st, EstState* s, const double2* x1, const double2* x2, int n_cap, const double* models,
                   const int* nmodels, double* medians, int H, int niters, int npairs) {
-    const size_t lds = (size_t)4 * (((n_cap + 3) & ~3) + 256) * sizeof(uint32_t);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lmeds_medians),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_lmeds_medians, dim3(cdiv(niters * 10, 4), npairs), dim3(256), lds, st, s, x1, x2, n_cap,
-                       models, nmodels, medians, H);
+    if (npairs <= 4) {
+        // a block per model: few pairs leave most of the chip idle, and the launch lasts one model's time
+        const size_t lds = (size_t)(((n_cap + 3) & ~3) + 256) * sizeof(uint32_t);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lmeds_medians_blk),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_lmeds_medians_blk, dim3(niters * 10, npairs), dim3(256), lds, st, s, x1, x2, n_cap,
+                           models, nmodels, medians, H);
+    } else {
+        const size_t lds = (size_t)4 * (((n_cap + 3) & ~3) + 256) * sizeof(uint32_t);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lmeds_medians),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_lmeds_medians, dim3(cdiv(niters * 10, 4), npairs), dim3(256), lds, st, s, x1, x2, n_cap,
+                           models, nmodels, medians, H);
+    }
     hipLaunchKernelGGL(k_lmeds_select, dim3(npairs), dim3(64), 0, st, s, nmodels, medians, H);
 }
 
