@@ -466,13 +466,15 @@ __global__ __launch_bounds__(256) void k_lmeds_medians_blk(const EstState* __res
 }
 
 // first strictly smaller median wins (hypotheses, then models, in order); sets the inlier threshold
-__global__ __launch_bounds__(64) void k_lmeds_select(EstState* __restrict__ st, const int* __restrict__ nmodels,
-                                                     const double* __restrict__ medians, int H) {
-    const int pair = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_lmeds_select(EstState* __restrict__ st, const int* __restrict__ nmodels,
+                                                      const double* __restrict__ medians, int H) {
+    __shared__ double s_best[4];
+    __shared__ int s_bi[4];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     EstState& s = st[pair];
     if (s.n == 5) {
         // cv solves once on all five points and marks them all inliers; the first model is kept
-        if (lane == 0) {
+        if (tid == 0) {
             s.best_h = nmodels[(size_t)pair * H] > 0 ? 0 : -1;
             s.best_m = 0;
             s.thr_f = __builtin_inff();
@@ -482,13 +484,23 @@ __global__ __launch_bounds__(64) void k_lmeds_select(EstState* __restrict__ st, 
     const int total = s.niters * 10;
     double best = DBL_MAX;
     int bi = 0x7fffffff;
-    for (int idx = lane; idx < total; idx += 64) {
-        const int h = idx / 10, m = idx % 10;
-        const size_t slot = (size_t)pair * H + h;
-        if (m < nmodels[slot]) {
-            const double v = medians[slot * 10 + m];
-            if (v < best) {
-                best = v;
+    // a slot's model count and its median are requested together (the median of a slot without a model is whatever
+    // the table holds and is not looked at): one round trip for the thread's slots instead of two per slot
+    for (int i0 = 0; i0 < total; i0 += 1024) {
+        int nm[4];
+        double mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = min(i0 + 256 * u + tid, total - 1);
+            const size_t slot = (size_t)pair * H + idx / 10;
+            nm[u] = nmodels[slot];
+            mv[u] = medians[slot * 10 + idx % 10];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = i0 + 256 * u + tid;
+            if (idx < total && idx % 10 < nm[u] && mv[u] < best) {
+                best = mv[u];
                 bi = idx;
             }
         }
@@ -503,6 +515,17 @@ __global__ __launch_bounds__(64) void k_lmeds_select(EstState* __restrict__ st, 
         }
     }
     if (lane == 0) {
+        s_best[tid >> 6] = best;
+        s_bi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; w++)
+            if (s_best[w] < best || (s_best[w] == best && s_bi[w] < bi)) {
+                best = s_best[w];
+                bi = s_bi[w];
+            }
         if (best < DBL_MAX) {
             s.best_h = bi / 10;
             s.best_m = bi % 10;
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(256) void k_pose_select(PoseState* __restrict__ ps,
                                                      int n_host, int n_cap, const double* __restrict__ q4,
                                                      const uint8_t* __restrict__ cmask, uint8_t* __restrict__ mask_out,
                                                      double* __restrict__ pts4) {
-    const int pair = blockIdx.x;
+    const int pair = blockIdx.y;
     PoseState& s = ps[pair];
     const int n = min(d_n ? d_n[pair] : n_host, n_cap);
     const int g0 = s.good[0], g1 = s.good[1], g2 = s.good[2], g3 = s.good[3];
@@ -664,13 +687,16 @@ __global__ __launch_bounds__(256) void k_pose_select(PoseState* __restrict__ ps,
     else if (g1 >= g0 && g1 >= g2 && g1 >= g3) win = 1;
     else if (g2 >= g0 && g2 >= g1 && g2 >= g3) win = 2;
     else win = 3;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        mask_out[(size_t)pair * n_cap + i] = cmask[((size_t)pair * 4 + win) * n_cap + i];
+    {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n) {
+            mask_out[(size_t)pair * n_cap + i] = cmask[((size_t)pair * 4 + win) * n_cap + i];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            pts4[((size_t)pair * 4 + k) * n_cap + i] = q4[(((size_t)pair * 4 + win) * 4 + k) * n_cap + i];
+            for (int k = 0; k < 4; k++)
+                pts4[((size_t)pair * 4 + k) * n_cap + i] = q4[(((size_t)pair * 4 + win) * 4 + k) * n_cap + i];
+        }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double* R = (win & 1) ? s.R2 : s.R1;
         const double sg = win < 2 ? 1.0 : -1.0;
 #pragma unroll
@@ -790,7 +816,7 @@ void launch_lmeds(hipStream_t st, EstState* s, const double2* x1, const double2*
         hipLaunchKernelGGL(k_lmeds_medians, dim3(cdiv(niters * 10, 4), npairs), dim3(256), lds, st, s, x1, x2, n_cap,
                            models, nmodels, medians, H);
     }
-    hipLaunchKernelGGL(k_lmeds_select, dim3(npairs), dim3(64), 0, st, s, nmodels, medians, H);
+    hipLaunchKernelGGL(k_lmeds_select, dim3(npairs), dim3(256), 0, st, s, nmodels, medians, H);
 }
 
 void launch_est_finish(hipStream_t st, EstState* s, const double2* x1, const double2* x2, int n_cap,
@@ -805,8 +831,8 @@ void launch_pose(hipStream_t st, const double* E, size_t e_stride, PoseState* ps
     if (n_grid > 0)
         hipLaunchKernelGGL(k_pose_points, dim3(cdiv(n_grid, 256), npairs, 2), dim3(256), 0, st, ps, x1, x2, d_n, n_host,
                            n_cap, mask_in, dist, q4, cmask);
-    hipLaunchKernelGGL(k_pose_select, dim3(npairs), dim3(256), 0, st, ps, d_n, n_host, n_cap, q4, cmask, mask_out,
-                       pts4);
+    hipLaunchKernelGGL(k_pose_select, dim3(std::max(cdiv(n_grid, 256), 1), npairs), dim3(256), 0, st, ps, d_n, n_host,
+                       n_cap, q4, cmask, mask_out, pts4);
 }
 
 __global__ __launch_bounds__(256) void k_pack_results(PackArgs a, uint32_t* __restrict__ out) {
