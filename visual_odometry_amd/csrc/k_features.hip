@@ -75,7 +75,6 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // run that path (the padding bytes beyond the 3-pixel frame get reflected values too; nothing reads
 // them as pixels).
 // ---------------------------------------------------------------------------------------------
-#define L0_ROWS 4    // rows per thread of the edge blocks
 #define L0_CHUNKS 4  // chunks per thread of the interior blocks: four independent 16-byte loads in flight
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, size_t frame_stride, int stride,
                                                     int w, int h, int pitch, unsigned pyr_bytes, unsigned loff,
@@ -111,24 +110,24 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
         for (int i = 0; i < L0_CHUNKS; i++)  // an index clamped to the last pair stores that pair again: same bytes
             *reinterpret_cast<uint4*>(dst + (ptrdiff_t)at[i]) = v[i];
     } else {
-        // edge chunks: x = -16, then end_int, end_int + 16, ... < w + 3
-        const int y0 = -3 + ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * L0_ROWS;
-        if (y0 >= h + 3) return;
+        // edge chunks: x = -16, then end_int, end_int + 16, ... < w + 3.  One thread per (row, edge chunk), the
+        // pairs of the frame in one sequence (a row has two or three such chunks: a thread per row and chunk column
+        // left 62 lanes of every wave idle, and these blocks were nine tenths of the kernel's instructions)
         const int nedge = 1 + (w + 3 - end_int + 15) / 16;
-        const int e = threadIdx.x & 63;
-        if (e >= nedge) return;
+        const int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+        const int row = idx / nedge, e = idx - row * nedge;
+        const int y = row - 3;
+        if (y >= h + 3) return;
         const int x16 = e == 0 ? -16 : end_int + 16 * (e - 1);
-        for (int i = 0; i < L0_ROWS && y0 + i < h + 3; i++) {
-            const uint8_t* src = fimg + (size_t)reflect101(y0 + i, h) * stride;
-            uint32_t d[4];
+        const uint8_t* src = fimg + (size_t)reflect101(y, h) * stride;
+        uint32_t d[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                d[q] = 0;
+        for (int q = 0; q < 4; q++) {
+            d[q] = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) d[q] |= (uint32_t)src[reflect101(x16 + 4 * q + j, w)] << (8 * j);
-            }
-            *reinterpret_cast<uint4*>(dst + (ptrdiff_t)(y0 + i) * pitch + x16) = make_uint4(d[0], d[1], d[2], d[3]);
+            for (int j = 0; j < 4; j++) d[q] |= (uint32_t)src[reflect101(x16 + 4 * q + j, w)] << (8 * j);
         }
+        *reinterpret_cast<uint4*>(dst + (ptrdiff_t)y * pitch + x16) = make_uint4(d[0], d[1], d[2], d[3]);
     }
 }
 
@@ -1933,7 +1932,8 @@ void launch_pyr_level0(hipStream_t st, const uint8_t* img, size_t frame_stride, 
     const int nch = L.w - 15 > 0 ? (L.w - 16) / 16 + 1 : 0;  // whole 16-byte chunks inside [0, w)
     const int nint = cdiv(nch * (L.h + 6), 256 * L0_CHUNKS);   // blocks of the interior
     const unsigned magic = nch > 1 ? (unsigned)((0x100000000ull + (unsigned)nch - 1) / (unsigned)nch) : 0xffffffffu;
-    const int nedge_blocks = cdiv(L.h + 6, 4 * L0_ROWS);
+    const int end_int = nch * 16;
+    const int nedge_blocks = cdiv((L.h + 6) * (1 + (L.w + 3 - end_int + 15) / 16), 256);
     dim3 grid(nedge_blocks + nint, 1, nframes);
     hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, st, img, frame_stride, stride, L.w, L.h, L.pitch,
                        hg.pyr_bytes, L.offset + (unsigned)(VO_PADY * L.pitch + VO_PADX), nedge_blocks, magic, pyr);
