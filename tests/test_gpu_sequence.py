@@ -337,3 +337,36 @@ def test_seq_multi_configs4_full_shape(oracle):
         Eg = np.array(r.E).reshape(3, 3)
         assert min(np.abs(Eg - o["E"]).max(), np.abs(Eg + o["E"]).max()) < 1e-6
         assert np.abs(np.array(r.R).reshape(3, 3) - o["R"]).max() < 1e-6 and np.abs(np.array(r.t) - o["t"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("mem", ["device", "pinned", "pageable"])
+def test_seq_shared_frames_are_carried_over_also_through_the_host_redo(seq_frames, batch_results, mem):
+    """Consecutive chunks share a frame; the runner gives every context a run of consecutive chunks and the
+    context carries the shared frame's keypoints over instead of describing it again.  Chunks of 2 pairs on 2
+    streams: most chunks start with a carried frame.  With a selection buffer of 64 entries every frame is
+    flagged and redone on the host path, so the carried rows are the redone ones; with the default buffer none
+    is.  Both must equal the one-batch results (which test_gpu_pipeline.py pins to the oracle), and the second
+    pass over the same runner starts from contexts that hold stale chunks."""
+    fr, _ = seq_frames
+    n = fr.shape[0]
+    keep = None
+    if mem == "device":
+        keep = torch.from_numpy(fr).to("cuda:0")
+        torch.cuda.synchronize()
+        src, m = keep.data_ptr(), api.MEM_DEVICE
+    elif mem == "pinned":
+        keep = torch.from_numpy(fr).pin_memory()
+        src, m = keep.data_ptr(), api.MEM_HOST_PINNED
+    else:
+        src, m = fr, api.MEM_HOST
+    for sel_cap in (None, 64):
+        seq = api.VoSequence(0, n_streams=2, pairs_per_chunk=2)
+        if sel_cap:
+            for i in range(2):
+                seq.ctx(i).set_option(api.OPT_SEL_CAP, sel_cap)
+        for _ in range(2):
+            res = seq.run(src, n, W, H, W, W * H, KS, api.pair_params(500), mem=m)
+            assert [as_tuple(r) for r in res] == batch_results
+            if sel_cap:
+                assert all(seq.ctx(i).get_option(api.OPT_LAST_FLAGS) & 1 for i in range(2))
+        seq.close()

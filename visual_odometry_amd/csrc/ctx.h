@@ -95,6 +95,7 @@ struct vo_ctx {
     int max_cand = 65536;  // candidates per frame the lists hold; grows when a frame has more
     int cand_nms = 1;      // nms flag of the last detection (to rewrite the lists after growing)
     int last_flags = 0;  // OR of the VO_SEL_* flags of the last batch
+    int feat_off = 0;    // chunk frame that the feature batch's frame 0 is (1: frame 0 carried over from the chunk before)
     int sel_cap = 6144;  // candidates per (frame, level) the device selection holds in LDS (72 KB)
     int kp_cap = 0;
     int feat_frames = 0;
@@ -240,8 +241,10 @@ int geom_recover_pose_dev(vo_ctx* c, int npairs, int n_cap, const double* d_E, s
                           const double* K, double dist_thresh, bool use_mask);
 
 // device-resident batch (vo_pipeline.cpp): queue everything / wait and fill the results
+// carry: frame 0 of the batch is the last frame of the batch this context ran before (same geometry and
+// parameters); its keypoints are taken over, d_frames points at frame 1, and n_frames still counts frame 0
 int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
-                 const double* K, const vo_pair_params* prm, bool details);
+                 const double* K, const vo_pair_params* prm, bool details, bool carry = false);
 int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out, size_t pair0);
 
 // profiling bracket (no-ops unless vo_prof_enable(ctx, 1))

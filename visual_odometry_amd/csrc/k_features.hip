@@ -1922,6 +1922,25 @@ __global__ __launch_bounds__(256) void k_orient_rbrief(const uint8_t* __restrict
     desc[((size_t)f * kp_cap + k) * 32 + b] = (uint8_t)val;
 }
 
+// The keypoints, descriptors and count of frame `from` of the chunk tables to frame 0: consecutive chunks of a
+// sequence share a frame, and the context that ran the chunk before still holds what it computed for it.
+__global__ __launch_bounds__(256) void k_carry_frame(vo_keypoint* __restrict__ kp, uint8_t* __restrict__ desc,
+                                                     int* __restrict__ nkp, int kp_cap, int from) {
+    const int n = min(nkp[from], kp_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[0] = n;
+    const uint32_t* ks = reinterpret_cast<const uint32_t*>(kp + (size_t)from * kp_cap);
+    uint32_t* kd = reinterpret_cast<uint32_t*>(kp);
+    const uint4* ds = reinterpret_cast<const uint4*>(desc + (size_t)from * kp_cap * 32);
+    uint4* dd = reinterpret_cast<uint4*>(desc);
+    static_assert(sizeof(vo_keypoint) == 28, "keypoints are copied as seven dwords");
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 7 * n; i += gridDim.x * 256) kd[i] = ks[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n; i += gridDim.x * 256) dd[i] = ds[i];
+}
+
+void launch_carry_frame(hipStream_t st, vo_keypoint* kp, uint8_t* desc, int* nkp, int kp_cap, int from) {
+    hipLaunchKernelGGL(k_carry_frame, dim3(16), dim3(256), 0, st, kp, desc, nkp, kp_cap, from);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------

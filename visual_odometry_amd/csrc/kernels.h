@@ -130,6 +130,7 @@ void launch_orb_select(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom
 void launch_ic_angle(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const Cand* sel, const int* flags,
                      int sel_fs, const Cand* selcand, const int* selcnt, int sel_cap, const int* nkp, int kp_cap,
                      int max_n, vo_keypoint* out, int nframes);
+void launch_carry_frame(hipStream_t st, vo_keypoint* kp, uint8_t* desc, int* nkp, int kp_cap, int from);
 void launch_gauss7(hipStream_t st, const uint8_t* pyr, const PyrGeom* d_geom, const PyrGeom& hg, uint8_t* blur,
                    const Taps7& taps, int nlevels_used, int nframes);
 void launch_rbrief(hipStream_t st, const PyrGeom* d_geom, const uint8_t* blur, const vo_keypoint* kps,

@@ -93,6 +93,7 @@ void retain_best(std::vector<RespIdx>& v, int n_points) {
 
 // Pyramid geometry for (w, h, params); p == nullptr -> single level (plain FAST).
 int feat_setup(vo_ctx* c, int w, int h, const vo_orb_params* p, int nframes) {
+    c->feat_off = 0;
     const int nlevels = p ? p->nlevels : 1;
     const float sf = p ? p->scale_factor : 1.2f;
     const int nfeatures = p ? p->nfeatures : 0;
@@ -332,7 +333,7 @@ int feat_select_dev(vo_ctx* c, int nframes, int n_bound) {
     // d_flags was zeroed by the detector of this batch (feat_detect)
     launch_orb_select(st, c->d_pyr.as<uint8_t>(), c->d_geom.as<PyrGeom>(), c->geom,
                       c->d_masks.as<unsigned long long>(), c->d_score.as<uint8_t>(), c->cand_nms, q, c->sel_cap,
-                      c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(), c->d_flags.as<int>(), c->d_nkp.as<int>(), n_bound,
+                      c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(), c->d_flags.as<int>(), c->d_nkp.as<int>() + c->feat_off, n_bound,
                       nframes, c->d_sel.as<Cand>(), c->kp_cap);
     return vo_check_launch(c, "keypoint selection");
 }
@@ -357,7 +358,8 @@ int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
     VO_TRY(feat_fetch_cands(c, nframes, redo.data()));
     VO_TRY(vo_ensure_pinned(c, c->h_sel, (size_t)nframes * c->kp_cap * sizeof(Cand)));
     const int* lv = c->h_lvlofs.as<int>();
-    int* nkp = c->h_nkp.as<int>();
+    // (feat_off: the batch's frame f is frame feat_off + f of the caller's chunk, whose tables the counts live in)
+    int* nkp = c->h_nkp.as<int>() + c->feat_off;
     // frames are independent: the (sequential, libstdc++-defined) selections run on host threads
     auto select_frame = [&](int f, std::vector<RespIdx>& v) -> int {
         const Cand* cand = c->h_cand.as<Cand>() + (size_t)f * c->max_cand;
@@ -402,7 +404,7 @@ int feat_select_host(vo_ctx* c, int nframes, int* max_n_out) {
                                      hipMemcpyHostToDevice, c->stream));
     }
     nkp[nframes] = 0;
-    VO_HIP(c, hipMemcpyAsync(c->d_nkp.p, nkp, (size_t)(nframes + 1) * sizeof(int), hipMemcpyHostToDevice,
+    VO_HIP(c, hipMemcpyAsync(c->d_nkp.as<int>() + c->feat_off, nkp, (size_t)(nframes + 1) * sizeof(int), hipMemcpyHostToDevice,
                              c->stream));
     for (int f = 0; f < nframes; f++) hflags[f] = redo[f] ? (hflags[f] ? hflags[f] : VO_SEL_OVERSIZE) : 0;
     VO_HIP(c, hipMemcpyAsync(c->d_flags.p, hflags, (size_t)nframes * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -416,6 +418,11 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
     static const Taps7 taps = gauss_taps();
     const PyrGeom& g = c->geom;
     const PyrGeom* dg = c->d_geom.as<PyrGeom>();
+    // the batch's outputs start at frame feat_off of the chunk's tables (1: frame 0 was carried over from the
+    // chunk before, see pairs_submit)
+    int* d_nkp = c->d_nkp.as<int>() + c->feat_off;
+    vo_keypoint* d_kp = c->d_kp.as<vo_keypoint>() + (size_t)c->feat_off * c->kp_cap;
+    uint8_t* d_desc = c->d_desc.as<uint8_t>() + (size_t)c->feat_off * c->kp_cap * 32;
     // host_selection = the redo of a batch whose first pass already blurred the pyramid
     if (!host_selection)
         launch_gauss7(c->stream, c->d_pyr.as<uint8_t>(), dg, g, c->d_blur.as<uint8_t>(), taps, g.nlevels, nframes);
@@ -424,16 +431,14 @@ int feat_describe(vo_ctx* c, int nframes, int max_n, bool angles, bool host_sele
         // d_sel: the device selection's lists flattened by k_sel_flatten, with the rows of flagged frames
         // replaced by the host selection in the redo
         launch_orient_rbrief(c->stream, c->d_pyr.as<uint8_t>(), c->d_blur.as<uint8_t>(), dg, c->d_sel.as<Cand>(),
-                             c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(),
-                             c->d_desc.as<uint8_t>(), nframes);
+                             d_nkp, c->kp_cap, max_n, d_kp, d_desc, nframes);
         return vo_check_launch(c, "feature description");
     }
     if (angles)
         launch_ic_angle(c->stream, c->d_pyr.as<uint8_t>(), dg, host_selection ? c->d_sel.as<Cand>() : nullptr,
                         c->d_flags.as<int>(), g.nlevels * c->sel_cap, c->d_selcand.as<Cand>(), c->d_selcnt.as<int>(),
-                        c->sel_cap, c->d_nkp.as<int>(), c->kp_cap, max_n, c->d_kp.as<vo_keypoint>(), nframes);
-    launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), c->d_kp.as<vo_keypoint>(), c->d_nkp.as<int>(),
-                  c->kp_cap, max_n, c->d_desc.as<uint8_t>(), nframes);
+                        c->sel_cap, d_nkp, c->kp_cap, max_n, d_kp, nframes);
+    launch_rbrief(c->stream, dg, c->d_blur.as<uint8_t>(), d_kp, d_nkp, c->kp_cap, max_n, d_desc, nframes);
     return vo_check_launch(c, "feature description");
 }
 

@@ -79,7 +79,7 @@ static void pairs_unpack(vo_ctx* c) {
 // Queue the whole batch on the context's stream without a host round trip: ORB with the
 // device-side keypoint selection, matching, essential matrix, pose, result copies.
 int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h, int stride, size_t frame_stride,
-                 const double* K, const vo_pair_params* prm, bool details) {
+                 const double* K, const vo_pair_params* prm, bool details, bool carry) {
     if (!d_frames || n_frames < 2 || w <= 0 || h <= 0 || stride < w || frame_stride < (size_t)stride * h || !K ||
         !prm)
         return c->fail(VO_ERR_INVALID, "vo_pairs_run_dev: bad argument");
@@ -87,17 +87,33 @@ int pairs_submit(vo_ctx* c, const uint8_t* d_frames, int n_frames, int w, int h,
         return c->fail(VO_ERR_CAPACITY, "nfeatures %d exceeds max_features %d", prm->orb.nfeatures,
                        c->lim.max_features);
     VO_HIP(c, hipSetDevice(c->device));
+    const int prev_frames = c->pipe_frames;  // frames of the batch this context collected last
     c->pipe_frames = 0;
     c->pend_frames = 0;
     c->pend_details = details;
+    if (carry && (prev_frames < 2 || c->geom_w != w || c->geom_h != h))
+        return c->fail(VO_ERR_INVALID, "pairs_submit: no frame to carry over");
+    const void *kp_before = c->d_kp.p, *desc_before = c->d_desc.p;
+    const int cap_before = c->kp_cap;
     VO_TRY(feat_setup(c, w, h, &prm->orb, n_frames));
+    if (carry && (c->d_kp.p != kp_before || c->d_desc.p != desc_before || c->kp_cap != cap_before))
+        return c->fail(VO_ERR_INVALID, "pairs_submit: the tables of the frame to carry over were reallocated");
     const int n_bound = feat_n_bound(c, prm->orb.nfeatures);
+    // Consecutive chunks of a sequence share a frame.  A context that runs them one after the other still holds
+    // the keypoints and descriptors of that frame (final ones: the chunk before was collected, host redo
+    // included): they move to row 0 of the tables and the detector starts at frame 1.
+    const int off = carry ? 1 : 0;
+    if (carry) {
+        launch_carry_frame(c->stream, c->d_kp.as<vo_keypoint>(), c->d_desc.as<uint8_t>(), c->d_nkp.as<int>(), c->kp_cap,
+                           prev_frames - 1);
+        c->feat_off = 1;
+    }
     {
         ProfScope ps(c, VO_PROF_FEATURES);
-        VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames, prm->orb.fast_threshold,
+        VO_TRY(feat_detect(c, d_frames, frame_stride, stride, n_frames - off, prm->orb.fast_threshold,
                            prm->orb.edge_threshold, 1, false));
-        VO_TRY(feat_select_dev(c, n_frames, n_bound));
-        VO_TRY(feat_describe(c, n_frames, n_bound, true, false));
+        VO_TRY(feat_select_dev(c, n_frames - off, n_bound));
+        VO_TRY(feat_describe(c, n_frames - off, n_bound, true, false));
     }
     VO_TRY(pairs_after_selection(c, n_frames, n_bound, K, prm));
     memcpy(c->pend_K, K, sizeof(c->pend_K));
@@ -117,13 +133,15 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out,
     VO_HIP(c, hipStreamSynchronize(c->stream));
     pairs_unpack(c);
     int flagged = 0;
-    for (int f = 0; f < n_frames; f++) flagged |= c->h_flags.as<int>()[f];
+    const int nf_feat = n_frames - c->feat_off;  // frames the feature stage ran on (flags are per such frame)
+    for (int f = 0; f < nf_feat; f++) flagged |= c->h_flags.as<int>()[f];
     c->last_flags = flagged;
     if (flagged) {
         // a frame the device selection could not finish exactly (VO_SEL_*): host selection, redo
         int max_n = 0;
-        VO_TRY(feat_select_host(c, n_frames, &max_n));
-        if (max_n > 0) VO_TRY(feat_describe(c, n_frames, max_n, true, true));
+        VO_TRY(feat_select_host(c, nf_feat, &max_n));
+        if (c->feat_off) max_n = std::max(max_n, c->h_nkp.as<int>()[0]);  // the carried frame's count
+        if (max_n > 0) VO_TRY(feat_describe(c, nf_feat, max_n, true, true));
         VO_TRY(pairs_after_selection(c, n_frames, max_n, c->pend_K, &c->pend_prm));
         VO_HIP(c, hipStreamSynchronize(c->stream));
         pairs_unpack(c);
@@ -300,38 +318,69 @@ struct ChunkDesc {
     size_t pair0;               // ... and the row of its first pair in them
 };
 
-// The pipeline over a list of chunks: chunk k on context k mod S, at most S in flight, results collected in
-// order.  Chunks of different sequences follow each other without draining the pipeline.
+// The pipeline over a list of chunks, at most S in flight, one per context.  The list is cut into S runs of
+// consecutive chunks, run r on context r: a context then meets the chunks of a sequence one after the other, and
+// the frame that two of them share is described once -- its keypoints are carried over on the device
+// (pairs_submit) instead of being computed again by the next chunk (1 / 49 of the detector's work at 48 pairs a
+// chunk, and of the upload).  Step i of the loop submits the (i / S)-th chunk of run i mod S, so the S contexts
+// are fed in turn as before; chunks of different sequences follow each other without draining the pipeline.
 int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, int h, int stride, size_t frame_stride,
                    const double* K, const vo_pair_params* prm) {
     const int S = (int)s->ctx.size(), B = s->chunk_pairs;
     const int nchunks = (int)ch.size();
     const size_t img = (size_t)w * h;
     int rc = VO_OK;
-    int collected = 0;  // chunks [0, collected) have their results
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     s->submit_ms = s->wait_ms = 0;
     s->chunks = nchunks;
     for (auto& P : s->pre) P.chunk[0] = P.chunk[1] = -1;  // nothing of this run is on the device yet
     const bool prefetch = s->ctx[0]->opt_seq_prefetch != 0;
-    auto collect = [&](int k) {
+    std::vector<int> rb((size_t)S + 1, 0);  // run r = chunks [rb[r], rb[r + 1])
+    for (int r = 0; r < S; r++) rb[(size_t)r + 1] = rb[(size_t)r] + nchunks / S + (r < nchunks % S ? 1 : 0);
+    const int steps = S * (nchunks / S + (nchunks % S ? 1 : 0));
+    auto chunk_of = [&](int step) {
+        if (step < 0 || step >= steps) return -1;
+        const int k = rb[(size_t)(step % S)] + step / S;
+        return k < rb[(size_t)(step % S) + 1] ? k : -1;
+    };
+    // chunk k starts with the last frame of chunk k - 1 of its run
+    auto carries = [&](int step) {
+        const int k = chunk_of(step);
+        if (k < 0 || step < S) return false;
+        const ChunkDesc &a = ch[(size_t)k - 1], &b = ch[(size_t)k];
+        return b.src == a.src + (size_t)(a.nf - 1) * frame_stride;
+    };
+    int collected = 0;  // steps [0, collected) have their results
+    auto collect = [&](int step) {
+        const int k = chunk_of(step);
+        if (k < 0) return (int)VO_OK;
+        vo_ctx* c = s->ctx[(size_t)(step % S)];
+        if (c->pend_frames < 2) return (int)VO_OK;
         const auto t0 = clk::now();
-        const int r = s->from(s->ctx[k % S], pairs_collect(s->ctx[k % S], ch[(size_t)k].res, ch[(size_t)k].out, ch[(size_t)k].pair0));
+        const int r = s->from(c, pairs_collect(c, ch[(size_t)k].res, ch[(size_t)k].out, ch[(size_t)k].pair0));
         s->wait_ms += ms_since(t0);
         return r;
     };
-    for (int k = 0; k < nchunks && rc == VO_OK; k++) {
-        const int slot = k % S;
-        vo_ctx* c = s->ctx[slot];
-        if (k - S >= collected) {  // the context still holds chunk k - S
-            rc = collect(k - S);
-            collected = k - S + 1;
+    for (int step = 0; step < steps && rc == VO_OK; step++) {
+        const int slot = step % S;
+        vo_ctx* c = s->ctx[(size_t)slot];
+        if (step - S >= collected) {  // the context still holds the chunk of step - S
+            rc = collect(step - S);
+            collected = step - S + 1;
             if (rc != VO_OK) break;
         }
+        const int k = chunk_of(step);
+        if (k < 0) continue;
         const bool details = ch[(size_t)k].out != nullptr;
         const int nf = ch[(size_t)k].nf;
-        const uint8_t* src = ch[(size_t)k].src;
+        const bool carry = carries(step) && c->pipe_frames == ch[(size_t)k - 1].nf;
+        if (carries(step) && !carry) {
+            rc = s->fail(VO_ERR_INVALID, "chunk %d: the context does not hold the chunk before it", k);
+            break;
+        }
+        const int off = carry ? 1 : 0;  // frames of the chunk that are not sent / described again
+        const uint8_t* src = ch[(size_t)k].src + (size_t)off * frame_stride;
         const auto t_submit = clk::now();
         struct Acc {
             vo_seq* s;
@@ -339,16 +388,16 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
             ~Acc() { s->submit_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
         } acc{s, t_submit};
         if (mem == VO_MEM_DEVICE) {
-            rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm, details));
+            rc = s->from(c, pairs_submit(c, src, nf, w, h, stride, frame_stride, K, prm, details, carry));
             continue;
         }
         // Pinned frames go up on the chunk's own stream in front of its kernels: the copies of the other chunks
         // overlap them, and no further streams compete for the process's hardware queues (108 k pairs/s against
         // 87 k with four chunks in flight).  VO_OPT_SEQ_PREFETCH = 1 (taken from the runner's first context at the
-        // start of the run): the earlier scheme, every context sends chunk k + S ahead of time on a copy stream of
-        // its own into a second image buffer.
+        // start of the run): the earlier scheme, every context sends its next chunk ahead of time on a copy stream
+        // of its own into a second image buffer.
         if (mem == VO_MEM_HOST_PINNED && stride == w && frame_stride == img && prefetch) {
-            vo_seq::Prefetch& P = s->pre[slot];
+            vo_seq::Prefetch& P = s->pre[(size_t)slot];
             const size_t need = (size_t)(B + 1) * img;
             hipError_t pe = hipSuccess;
             if (!P.copy) pe = hipStreamCreateWithFlags(&P.copy, hipStreamNonBlocking);
@@ -365,41 +414,45 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
                 }
                 P.cap = pe == hipSuccess ? need : 0;
             }
-            auto upload = [&](int chunk, int b) {
-                hipError_t e2 = hipMemcpyAsync(P.img[b], ch[(size_t)chunk].src, (size_t)ch[(size_t)chunk].nf * img,
-                                               hipMemcpyHostToDevice, P.copy);
+            auto upload = [&](int st, int b) {  // the frames the chunk of step st will describe
+                const int kk = chunk_of(st);
+                const int o = carries(st) ? 1 : 0;
+                hipError_t e2 = hipMemcpyAsync(P.img[b], ch[(size_t)kk].src + (size_t)o * img,
+                                               (size_t)(ch[(size_t)kk].nf - o) * img, hipMemcpyHostToDevice, P.copy);
                 if (e2 == hipSuccess) e2 = hipEventRecord(P.ev[b], P.copy);
-                P.chunk[b] = chunk;
+                P.chunk[b] = kk;
                 return e2;
             };
-            const int b = (k / S) & 1;
-            if (pe == hipSuccess && P.chunk[b] != k) pe = upload(k, b);  // first chunks of a run: nothing prefetched
+            const int b = (step / S) & 1;
+            if (pe == hipSuccess && P.chunk[b] != k) pe = upload(step, b);  // first chunks of a run: nothing prefetched
             if (pe == hipSuccess) pe = hipStreamWaitEvent(c->stream, P.ev[b], 0);
             if (pe != hipSuccess) {
                 rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(pe));
                 break;
             }
-            rc = s->from(c, pairs_submit(c, static_cast<const uint8_t*>(P.img[b]), nf, w, h, w, img, K, prm, details));
-            // the other buffer held chunk k - S, which has been collected: send chunk k + S into it now
-            if (rc == VO_OK && k + S < nchunks && upload(k + S, b ^ 1) != hipSuccess)
+            rc = s->from(c, pairs_submit(c, static_cast<const uint8_t*>(P.img[b]), nf, w, h, w, img, K, prm, details,
+                                         carry));
+            // the other buffer held the chunk of step - S, which has been collected: send the next one into it now
+            if (rc == VO_OK && chunk_of(step + S) >= 0 && upload(step + S, b ^ 1) != hipSuccess)
                 rc = s->fail(VO_ERR_DEVICE, "frame prefetch failed");
             continue;
         }
         // host frames: tightly packed copy of the chunk into the context's image buffer
         if ((rc = s->from(c, vo_ensure(c, c->d_img, (size_t)(B + 1) * img))) != VO_OK) break;
         hipError_t e = hipSuccess;
+        const int nsend = nf - off;
         if (mem == VO_MEM_HOST) {
             // pageable memory: stage through pinned memory so that the copy is one asynchronous DMA
-            if ((rc = s->from(c, vo_ensure_pinned(c, s->stage[slot], (size_t)(B + 1) * img))) != VO_OK) break;
-            uint8_t* st = s->stage[slot].as<uint8_t>();
-            for (int f = 0; f < nf; f++)
+            if ((rc = s->from(c, vo_ensure_pinned(c, s->stage[(size_t)slot], (size_t)(B + 1) * img))) != VO_OK) break;
+            uint8_t* st = s->stage[(size_t)slot].as<uint8_t>();
+            for (int f = 0; f < nsend; f++)
                 for (int y = 0; y < h; y++)
                     memcpy(st + (size_t)f * img + (size_t)y * w, src + (size_t)f * frame_stride + (size_t)y * stride, w);
-            e = hipMemcpyAsync(c->d_img.p, st, (size_t)nf * img, hipMemcpyHostToDevice, c->stream);
+            e = hipMemcpyAsync(c->d_img.p, st, (size_t)nsend * img, hipMemcpyHostToDevice, c->stream);
         } else if (stride == w && frame_stride == img) {
-            e = hipMemcpyAsync(c->d_img.p, src, (size_t)nf * img, hipMemcpyHostToDevice, c->stream);
+            e = hipMemcpyAsync(c->d_img.p, src, (size_t)nsend * img, hipMemcpyHostToDevice, c->stream);
         } else {
-            for (int f = 0; f < nf && e == hipSuccess; f++)
+            for (int f = 0; f < nsend && e == hipSuccess; f++)
                 e = hipMemcpy2DAsync(c->d_img.as<uint8_t>() + (size_t)f * img, w, src + (size_t)f * frame_stride, stride,
                                      w, h, hipMemcpyHostToDevice, c->stream);
         }
@@ -407,16 +460,16 @@ int seq_run_chunks(vo_seq* s, const std::vector<ChunkDesc>& ch, int mem, int w, 
             rc = s->fail(VO_ERR_DEVICE, "frame upload failed: %s", hipGetErrorString(e));
             break;
         }
-        rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm, details));
+        rc = s->from(c, pairs_submit(c, c->d_img.as<uint8_t>(), nf, w, h, w, img, K, prm, details, carry));
     }
     if (rc != VO_OK)
         for (auto& P : s->pre)
             if (P.copy) (void)hipStreamSynchronize(P.copy);  // a prefetch nobody will wait for
     // drain in order (also after an error, so that no context is left with work in flight)
-    for (int k = collected; k < nchunks; k++) {
-        vo_ctx* c = s->ctx[k % S];
-        if (c->pend_frames < 2) continue;
-        if (rc == VO_OK) rc = collect(k);
+    for (int step = collected; step < steps; step++) {
+        vo_ctx* c = s->ctx[(size_t)(step % S)];
+        if (chunk_of(step) < 0 || c->pend_frames < 2) continue;
+        if (rc == VO_OK) rc = collect(step);
         else {
             (void)hipStreamSynchronize(c->stream);
             c->pend_frames = 0;
