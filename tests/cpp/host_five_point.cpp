@@ -29,3 +29,14 @@ extern "C" void host_triangulate_point_mirror(const double* P0, const double* P1
                                               const double* x1, double* X, double* Xm) {
     triangulate_point(P0, P1, x0[0], x0[1], x1[0], x1[1], X, Xm);
 }
+
+// the two forms of the RANSAC inlier test: (float)error <= thr, and the division-free decision used by k_score
+extern "C" void host_sampson_both(const double* E, const double* x1, const double* x2, int n, float thr,
+                                  unsigned char* by_error, unsigned char* by_bound, float* err) {
+    const double M = sampson_bound(thr);
+    for (int i = 0; i < n; i++) {
+        err[i] = sampson_error(E, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]);
+        by_error[i] = err[i] <= thr;
+        by_bound[i] = sampson_inlier(E, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1], thr, M);
+    }
+}

@@ -153,3 +153,32 @@ def test_mirrored_triangulation_is_bit_identical_to_a_second_decomposition(host)
         checked += 1
         swapped += bool(np.signbit(Xm[0]) != np.signbit(X[0]))  # the tracked sign of the row flipped on the way
     assert checked == 4000 and 100 < swapped < 3900  # both outcomes of the sign tracking occur
+
+
+def test_division_free_inlier_test_equals_the_float_comparison(host):
+    """k_score / k_est_finish decide `(float)sampson <= thr` by comparing the numerator with M * denominator (M the
+    midpoint between thr and the next float) and divide only in a 2^-48 sliver around it.  Same decision for every
+    point, including thresholds placed ON a point's error, one float below and above it, zero, infinity, and
+    degenerate models (zero matrix: 0 / 0)."""
+    rng = np.random.default_rng(11)
+    n = 4000
+    for trial in range(30):
+        p0, p1, R, t, _ = synth.correspondences(n, seed=100 + trial, inlier_ratio=0.6)
+        x1 = np.ascontiguousarray(np.stack([(p0[:, 0] - K[0, 2]) / K[0, 0], (p0[:, 1] - K[1, 2]) / K[1, 1]], 1), np.float64)
+        x2 = np.ascontiguousarray(np.stack([(p1[:, 0] - K[0, 2]) / K[0, 0], (p1[:, 1] - K[1, 2]) / K[1, 1]], 1), np.float64)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        E = tx @ R
+        E = np.ascontiguousarray(E / np.linalg.norm(E) + (rng.normal(0, 1e-3, (3, 3)) if trial % 2 else 0))
+        if trial == 29:
+            E = np.zeros((3, 3))
+        a, b, err = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+        host.host_sampson_both(_p(E), _p(x1), _p(x2), n, C.c_float(1.0), _p(a), _p(b), _p(err))
+        fin = err[np.isfinite(err)]
+        picks = list(rng.choice(fin, 12)) if len(fin) else []
+        thrs = [0.0, np.inf, (1.0 / 718.856) ** 2, 1e-12, 3e38]
+        for e in picks:
+            thrs += [e, np.nextafter(np.float32(e), np.float32(np.inf)), np.nextafter(np.float32(e), np.float32(-1))]
+        for thr in thrs:
+            thr = float(max(np.float32(thr), np.float32(0)))
+            host.host_sampson_both(_p(E), _p(x1), _p(x2), n, C.c_float(thr), _p(a), _p(b), _p(err))
+            assert np.array_equal(a, b), (trial, thr, np.nonzero(a != b)[0][:5])

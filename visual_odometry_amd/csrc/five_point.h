@@ -702,4 +702,38 @@ VO_HD float sampson_error(const double* E, double a1, double b1, double a2, doub
     return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
 }
 
+// sampson_error(...) <= thr without the division, for the RANSAC counts (the same decision, bit for bit).
+// (float)q <= thr for a double q holds iff q lies below M, the midpoint of thr and the float after it (a tie at M
+// goes to the even neighbour and is left to the exact expression).  With q = fl(num / den): num < M den (1 - 2^-48)
+// puts the real quotient, and with it its rounding, below M; num > M den (1 + 2^-48) puts them above; the sliver in
+// between, a product that underflows, a zero denominator and NaNs take the division.  sampson_bound(thr) is M.
+VO_HD double sampson_bound(float thr) {
+    if (!(thr < 3.0e38f)) return (double)thr;  // inf (LMedS with five points: everything is an inlier), NaN
+    union {
+        float f;
+        unsigned u;
+    } v;
+    v.f = thr;  // thr >= 0: a squared distance
+    v.u += 1;
+    return ((double)thr + (double)v.f) * 0.5;
+}
+VO_HD bool sampson_inlier(const double* E, double a1, double b1, double a2, double b2, float thr, double M) {
+    const double Ex0 = E[0] * a1 + E[1] * b1 + E[2] * 1.0;
+    const double Ex1 = E[3] * a1 + E[4] * b1 + E[5] * 1.0;
+    const double Ex2 = E[6] * a1 + E[7] * b1 + E[8] * 1.0;
+    const double Et0 = E[0] * a2 + E[3] * b2 + E[6] * 1.0;
+    const double Et1 = E[1] * a2 + E[4] * b2 + E[7] * 1.0;
+    const double x2tEx1 = a2 * Ex0 + b2 * Ex1 + 1.0 * Ex2;
+    const double a = Ex0 * Ex0;
+    const double b = Ex1 * Ex1;
+    const double c = Et0 * Et0;
+    const double d = Et1 * Et1;
+    const double num = x2tEx1 * x2tEx1, den = a + b + c + d;
+    const double p = M * den;
+    const double eps = 3.5527136788005009e-15;  // 2^-48
+    if (p > 1e-290 && num < p * (1.0 - eps)) return true;
+    if (p > 1e-290 && num > p * (1.0 + eps)) return false;
+    return (float)(num / den) <= thr;
+}
+
 #endif

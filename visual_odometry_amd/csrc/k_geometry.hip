@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void k_score(int h0, int h1, const EstState* _
     __builtin_amdgcn_wave_barrier();
     const int n = s.n;
     const float thr = s.thr_f;
+    const double thr_m = sampson_bound(thr);
     int cnt[10];
 #pragma unroll
     for (int m = 0; m < 10; m++) cnt[m] = 0;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void k_score(int h0, int h1, const EstState* _
 #pragma unroll
         for (int m = 0; m < 10; m++) {
             if (m < nm) {
-                const float err = sampson_error(&Es[wv][9 * m], u.x, u.y, v.x, v.y);
-                cnt[m] += __popcll(__ballot(ok && err <= thr));
+                const bool inl = sampson_inlier(&Es[wv][9 * m], u.x, u.y, v.x, v.y, thr, thr_m);
+                cnt[m] += __popcll(__ballot(ok && inl));
             }
         }
     }
@@ -560,13 +561,14 @@ __global__ __launch_bounds__(256) void k_est_finish(EstState* __restrict__ st, c
 #pragma unroll
     for (int k = 0; k < 9; k++) E[k] = models[slot * 90 + 9 * s.best_m + k];
     const float thr = s.thr_f;
+    const double thr_m = sampson_bound(thr);
     int cnt = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + threadIdx.x;
         bool inl = false;
         if (i < n) {
             const double2 u = x1[(size_t)pair * n_cap + i], v = x2[(size_t)pair * n_cap + i];
-            inl = sampson_error(E, u.x, u.y, v.x, v.y) <= thr;
+            inl = sampson_inlier(E, u.x, u.y, v.x, v.y, thr, thr_m);
             mk[i] = inl ? 1 : 0;
         }
         cnt += __popcll(__ballot(inl));
