@@ -134,14 +134,16 @@ int geom_find_essential_dev(vo_ctx* c, int npairs, int n_cap, const float2* d_p0
         // hypotheses are evaluated in growing chunks; a chunk whose first index is already past
         // the (shrinking) iteration cap exits at once, so typical inputs run only the first one
         // or two, with the same result as evaluating all of them.
-        // The first round is sized so that a 32-pair batch is one partly filled wave per SIMD (one
-        // solve latency; 128 per pair measured 30 % slower); every further round costs three launches
-        // even when it exits at once, so the rounds grow by 4x: 64, 256, 680 for cv's 1000.
+        // Every round costs three launches even when it exits at once, so the rounds grow by 4x: 32, 128, 512,
+        // 328 for cv's 1000.  The first round is what every pair pays in full: with the matcher's ratio test in
+        // front, most pairs reach their iteration cap within twenty hypotheses, and the ones solved and scored
+        // beyond it are wasted fp64 work beside the other chunks' kernels (first round 64: 146.5 k pairs/s, 32:
+        // 149.7 k, 24: the same, 16: 148.0 k on one box; 128 measured 30 % slower in round 2).
         // A call for one or two pairs is a latency measurement, not a throughput one (BASELINE configs[1]): the chip
         // is idle, 1 000 hypotheses solve and score in the time 64 do, and every extra round is three more dependent
         // launches, so they all go out at once.  Which hypothesis wins does not depend on the rounds: k_replay applies
         // cv's sequential rule to the counts in hypothesis order and ignores those past the (shrinking) cap.
-        int h0 = 0, size = npairs <= 2 ? std::min(H, 1024) : 64;
+        int h0 = 0, size = npairs <= 2 ? std::min(H, 1024) : 32;
         while (h0 < H) {
             const int h1 = std::min(H, h0 + size);
             {
