@@ -246,7 +246,7 @@ def test_pair_results_do_not_depend_on_the_chunk_size(seq_frames, ratio):
     five-point solver used to be chosen from hypotheses x pairs of a launch, and the two solvers are not
     bit-identical).  The same 48 pairs in one chunk of 48, in chunks of 5 and one pair at a time through
     vo_pairs_run_dev: identical results, bit for bit.  ratio 0.97 lets many wrong matches through, so the
-    adaptive RANSAC runs its later, larger rounds (64 -> 256 -> 680 hypotheses) as well."""
+    adaptive RANSAC runs its later, larger rounds (32 -> 128 -> 512 -> 328 hypotheses) as well."""
     fr, _ = seq_frames
     n = 49
     idx = synth.pingpong_indices(fr.shape[0], n)
