@@ -254,8 +254,9 @@ int vo_pairs_get_matches(vo_ctx* ctx, int pair, vo_dmatch* good, uint8_t* inlier
  * VisualOdometry::addImage, src/visual_odometry/visual_odometry.cpp:20-68) for the descriptor
  * path: n_frames consecutive frames in, one vo_pair_result per consecutive pair out, identical to
  * what vo_pairs_run_dev returns for the same frames.  The sequence is cut into chunks of
- * pairs_per_chunk pairs (neighbouring chunks share a frame); chunk k runs on stream k mod n_streams
- * with its own workspace, so uploads and the latency-bound stages of one chunk overlap the
+ * pairs_per_chunk pairs (neighbouring chunks share a frame); the chunk list is split into n_streams runs of
+ * consecutive chunks, run r on stream r with its own workspace (the stream describes the shared frame of two of
+ * its chunks once), the streams are fed in turn, so uploads and the latency-bound stages of one chunk overlap the
  * streaming stages of the others.  `mem` says where `frames` lives: VO_MEM_DEVICE (HBM),
  * VO_MEM_HOST (pageable; staged through pinned memory) or VO_MEM_HOST_PINNED (hipHostMalloc'ed /
  * registered memory; copied by DMA directly).  Not thread-safe; one runner per host thread. */

@@ -193,7 +193,7 @@ int pairs_collect(vo_ctx* c, vo_pair_result* results, const vo_seq_outputs* out,
 
 // ---------------------------------------------------------------------------------------------
 // Sequence runner: a long sequence cut into chunks of `chunk_pairs` frame pairs (consecutive chunks
-// share one frame), chunk k on context k mod n_streams.  Every context has its own HIP stream and
+// share one frame), a run of consecutive chunks per context (seq_run_chunks).  Every context has its own HIP stream and
 // workspace, so the latency-bound stages of one chunk (keypoint selection, five-point solves,
 // RANSAC replay) run while the other chunks' streaming stages use the rest of the chip, and the
 // upload of a chunk overlaps the kernels of the chunks before it.
